@@ -1,0 +1,26 @@
+# Builds the gfx950 library (product) and the CPU oracle (test infrastructure).
+#   make            -> raytracer_amd/librt_hip.so + oracle/liboracle.so
+# hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off on both sides: the reference's JIT never
+# fuses a*b+c, and the bit-exact parity of K / hit ids depends on one rounding per operator.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Wall -Wno-unused-function
+ORCFLAGS ?= -O2 -std=c++17 -march=x86-64-v3 -ffp-contract=off -fno-fast-math -fPIC -Wall -pthread
+
+CSRC := raytracer_amd/csrc
+LIB  := raytracer_amd/librt_hip.so
+ORC  := oracle/liboracle.so
+
+all: $(LIB) $(ORC)
+
+$(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h include/rt_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_lib.hip $(CSRC)/rt_bvh.cpp
+
+$(ORC): oracle/oracle.cpp include/rt_hip.h
+	$(CXX) $(ORCFLAGS) -shared -o $@ oracle/oracle.cpp
+
+clean:
+	rm -f $(LIB) $(ORC)
+
+.PHONY: all clean

@@ -1,0 +1,350 @@
+/*
+ * rt_hip.h — C ABI of the MI355X (gfx950) backend for the per-sample trace loop of
+ * Ararem.RayTracer's RenderJob.
+ *
+ * The reference has no FFI of its own: the boundary this library replaces is the body of
+ * RenderJob.RenderInternal (Ararem.RayTracer.Core/RenderJob.cs:69-126) and everything it calls.
+ * A C# backend (csharp/HipRenderBackend.cs) flattens the Scene graph into
+ * the plain-old-data tables below and drives the entry points through P/Invoke.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success and a negative rt_status on failure;
+ *     rt_last_error() returns a thread-local, NUL-terminated UTF-8 description of the last failure.
+ *   - the caller owns every host pointer; the library copies what it needs during the call.
+ *   - one handle => one calling thread at a time; different handles are independent.
+ *   - all floating-point is IEEE binary32, vectors are x,y,z, matrices follow System.Numerics
+ *     (row-vector convention: v' = v * M, element Mrc = row r, column c).
+ *   - an object's id is its index in rt_scene_desc.objects (== index in Scene.SceneObjects);
+ *     a material's id is its index in rt_scene_desc.materials (one entry per distinct Material
+ *     *reference*: RefractiveMaterial.cs:41-42 and EmissiveRefractiveMaterial.cs:27-33 compare
+ *     materials by identity).
+ *   - user-defined Hittable/Material/Texture/Light/SkyBox subclasses have no table here: the
+ *     flattener must reject them (no CPU fallback exists in this library).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef struct rt_scene  rt_scene;   /* opaque: flattened Scene + BVH on one device */
+typedef struct rt_render rt_render;  /* opaque: one RenderJob's device state */
+
+typedef enum rt_status {
+    RT_OK                = 0,
+    RT_ERR_INVALID_ARG   = -1, /* null pointer, bad enum, inconsistent table sizes */
+    RT_ERR_UNSUPPORTED   = -2, /* type the kernels do not implement */
+    RT_ERR_NO_DEVICE     = -3, /* no gfx950 device visible, or HIP runtime missing */
+    RT_ERR_HIP           = -4, /* a HIP runtime call failed; see rt_last_error() */
+    RT_ERR_OUT_OF_MEMORY = -5,
+    RT_ERR_TOO_LARGE     = -6  /* size beyond a documented limit */
+} rt_status;
+
+/* ------------------------------------------------------------------------------------------
+ * Hittables  (Ararem.RayTracer.Impl/Hittables).  Each record holds exactly the fields the
+ * reference's TryHit/FastTryHit read, including the values its constructor caches, so that a
+ * flattener inside the C# class can copy private fields verbatim.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum rt_hittable_type {
+    RT_HIT_SPHERE         = 0,  /* Sphere.cs */
+    RT_HIT_QUAD           = 1,  /* Quad.cs */
+    RT_HIT_TRIANGLE       = 2,  /* NEW (no reference counterpart; defined by analogy with Quad, SURVEY §8a row aT) */
+    RT_HIT_INFINITE_PLANE = 3,  /* InfinitePlane.cs */
+    RT_HIT_XY_PLANE       = 4,  /* XYPlane.cs */
+    RT_HIT_XZ_PLANE       = 5,  /* XZPlane.cs */
+    RT_HIT_YZ_PLANE       = 6,  /* YZPlane.cs */
+    RT_HIT_DISK           = 7,  /* Disk.cs */
+    RT_HIT_BOX            = 8,  /* Box.cs */
+    RT_HIT_CAPSULE        = 9,  /* Capsule.cs */
+    RT_HIT_CYLINDER       = 10, /* Cylinder.cs */
+    RT_HIT_MEDIUM         = 11, /* ConstantDensityMedium.cs */
+    RT_HIT_TYPE_COUNT     = 12
+} rt_hittable_type;
+
+typedef struct rt_sphere {           /* Sphere.cs:17-22 (radiusSqr = radius*radius is recomputed) */
+    float centre[3];
+    float radius;
+} rt_sphere;
+
+typedef struct rt_quad {             /* Quad.cs:37-55 */
+    float origin[3];
+    float normal[3];                 /* Normalize(Cross(u, v)) */
+    float inv_col1[4];               /* localToQuadMatrix M11, M21, M31, M41 (Quad.cs:107) */
+    float inv_col2[4];               /* localToQuadMatrix M12, M22, M32, M42 (Quad.cs:108) */
+} rt_quad;
+
+typedef struct rt_triangle {         /* NEW primitive, see rt_hittable_type */
+    float v0[3];
+    float e1[3];                     /* v1 - v0 */
+    float e2[3];                     /* v2 - v0 */
+    float normal[3];                 /* Normalize(Cross(e1, e2)), never flipped (as Quad) */
+    float inv_col1[4];               /* same construction as rt_quad with u=e1, v=e2 */
+    float inv_col2[4];
+} rt_triangle;
+
+typedef struct rt_infinite_plane {   /* InfinitePlane.cs:12-20; normal is NOT normalised by the ctor */
+    float point[3];
+    float normal[3];
+    float neg_point_dot_normal;
+} rt_infinite_plane;
+
+typedef struct rt_axis_plane {       /* XYPlane.cs:19-29 (a=x,b=y,c=z) / XZPlane.cs:19-29 (a=x,b=z,c=y) / YZPlane.cs:17-26 (a=y,b=z,c=x) */
+    float a_lo, a_hi;
+    float b_lo, b_hi;
+    float c;
+} rt_axis_plane;
+
+typedef struct rt_disk {             /* Disk.cs:23-41 */
+    float centre[3];
+    float normal[3];                 /* normalised by the ctor */
+    float radius;
+    float neg_centre_dot_norm;
+    float inv_col1[4];               /* localToDiskMatrix M11, M21, M31, M41 */
+    float inv_col2[4];               /* localToDiskMatrix M12, M22, M32, M42 */
+} rt_disk;
+
+typedef struct rt_box {              /* Box.cs:35-65 */
+    float world_to_box[12];          /* WorldToBoxTransform rows 1..4, columns 1..3: M11 M12 M13 M21 ... M43 */
+    float box_to_world_rows[9];      /* boxToWorldRow1, Row2, Row3 (Box.cs:62-64) */
+} rt_box;
+
+typedef struct rt_capsule {          /* Capsule.cs:35-55 */
+    float p1[3];
+    float p2[3];
+    float radius;
+    float uv_matrix[9];              /* uvMatrix M11 M12 M13 M21 M22 M23 M31 M32 M33 (Capsule.cs:48) */
+} rt_capsule;
+
+typedef struct rt_cylinder {         /* Cylinder.cs:28-40 */
+    float p1[3];
+    float p2[3];
+    float radius;
+} rt_cylinder;
+
+typedef struct rt_medium {           /* ConstantDensityMedium.cs:23-30 */
+    uint32_t boundary_type;          /* rt_hittable_type of Boundary (not RT_HIT_MEDIUM) */
+    uint32_t boundary_index;         /* index into that type's table */
+    float    density;
+    float    neg_inv_density;        /* -1f / density */
+} rt_medium;
+
+/* One entry per Scene.SceneObjects element, in order (SceneObject.cs:6-8).
+ * aabb = Hittable.BoundingVolume exactly as the reference computes it (may be +-infinity,
+ * InfinitePlane.cs:28; such objects are kept outside the BVH). */
+typedef struct rt_object {
+    uint32_t type;                   /* rt_hittable_type */
+    uint32_t index;                  /* index into the table of that type */
+    uint32_t material;               /* index into materials (the Hittable's Material) */
+    float    aabb_min[3];
+    float    aabb_max[3];
+} rt_object;
+
+/* ------------------------------------------------------------------------------------------
+ * Textures (Impl/Textures), materials (Impl/Materials), lights (Impl/Lights), skyboxes.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum rt_texture_type {
+    RT_TEX_SOLID  = 0,               /* SolidColourTexture.cs:14 : f[0..2] = colour */
+    RT_TEX_MARBLE = 1                /* MarbleTexture.cs:18-48  : f[0]=Scale f[1]=NoiseScale f[2]=NoiseStrength f[3]=DropoffPower */
+} rt_texture_type;
+
+typedef struct rt_texture {
+    uint32_t type;
+    float    f[7];
+} rt_texture;
+
+typedef enum rt_material_type {
+    RT_MAT_STANDARD            = 0,  /* StandardMaterial.cs  : tex[0]=Albedo tex[1]=Emission f[0]=Diffusion */
+    RT_MAT_REFRACTIVE          = 1,  /* RefractiveMaterial.cs: tex[0]=Tint f[0]=RefractiveIndex flags bit0=AlternateRefractionMode */
+    RT_MAT_EMISSIVE_REFRACTIVE = 2,  /* EmissiveRefractiveMaterial.cs: as above + tex[1]=Emission, flags bit1=DirectEmission */
+    RT_MAT_PHONG               = 3,  /* PhongMaterial.cs     : f[0..2]=Specular f[3..5]=Diffuse f[6..8]=Ambient f[9]=Shininess */
+    RT_MAT_VOLUMETRIC          = 4   /* ConstantDensityMedium.cs:87-130 : f[0..2]=Albedo f[3]=Density */
+} rt_material_type;
+
+#define RT_MAT_FLAG_ALTERNATE_REFRACTION 1u
+#define RT_MAT_FLAG_DIRECT_EMISSION      2u
+
+typedef struct rt_material {
+    uint32_t type;
+    uint32_t tex[2];
+    uint32_t flags;
+    float    f[10];
+} rt_material;
+
+typedef enum rt_light_type {
+    RT_LIGHT_POINT          = 0,     /* PointLight.cs:7 */
+    RT_LIGHT_DIFFUSE_SPHERE = 1,     /* DiffuseSphereLight.cs:85-139 (the hard-wired `case 4`) */
+    RT_LIGHT_DIFFUSE_SHAPED = 2      /* DiffuseShapedLight.cs:67-103 */
+} rt_light_type;
+
+/* SimpleLightBase.DistanceAttenuationFunc is a delegate (SimpleLightBase.cs:55-79); the flattener
+ * classifies it into one of the factory families below or rejects the light. x = kMax / AttenuationRadius. */
+typedef enum rt_attenuation_kind {
+    RT_ATTEN_CONSTANT        = 0,    /* p[0]                        (e.g. BuiltinScenes.cs:146 `(_, _) => 1f`) */
+    RT_ATTEN_LINEAR          = 1,    /* 1 - x                        SimpleLightBase.cs:56 */
+    RT_ATTEN_POWER           = 2,    /* Pow(1 - x, p[0])             :63 */
+    RT_ATTEN_POWER_STAY_HIGH = 3,    /* 1 - Pow(x, p[0])             :65 */
+    RT_ATTEN_LOGISTIC        = 4,    /* 1 / (1 + Pow(E, p[1] * (x - p[0])))   midpoint p[0], steepness p[1]  :70 */
+    RT_ATTEN_LOGISTIC_LKX    = 5,    /* p[0] / (1 + Pow(E, -p[1] * (x - p[2])))                              :73 */
+    RT_ATTEN_EXP_DECAY       = 6     /* Pow(E, p[0] * -x)            :75 (default, p[0]=5, :77) */
+} rt_attenuation_kind;
+
+typedef struct rt_light {
+    uint32_t type;
+    float    position[3];
+    float    colour[3];
+    float    attenuation_radius;     /* SimpleLightBase.cs:15 */
+    float    cutoff_radius;          /* :17 */
+    float    diffusion_radius;       /* DiffuseSphereLight.cs:11 */
+    uint32_t atten_kind;
+    float    atten_p[3];
+    uint32_t shape_type;             /* DIFFUSE_SHAPED: rt_hittable_type of Shape ... */
+    uint32_t shape_index;            /* ... and its index in that table (need not be a scene object) */
+    float    shape_aabb_min[3];      /* Shape.BoundingVolume */
+    float    shape_aabb_max[3];
+} rt_light;
+
+typedef enum rt_skybox_type {
+    RT_SKY_DEFAULT       = 0,        /* DefaultSkyBox.cs:10-14 */
+    RT_SKY_SINGLE_COLOUR = 1         /* SingleColourSkyBox.cs:16 */
+} rt_skybox_type;
+
+typedef struct rt_skybox {
+    uint32_t type;
+    float    colour[3];
+} rt_skybox;
+
+typedef struct rt_camera {           /* the fields Camera.GetRay reads, Camera.cs:35-42 */
+    float look_from[3];
+    float horizontal[3];
+    float vertical[3];
+    float lower_left_corner[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+} rt_camera;
+
+typedef struct rt_scene_desc {
+    uint32_t struct_size;            /* sizeof(rt_scene_desc) */
+    uint32_t abi_version;            /* RT_ABI_VERSION */
+    rt_camera camera;
+    rt_skybox skybox;
+    uint32_t n_objects;         const rt_object*         objects;
+    uint32_t n_spheres;         const rt_sphere*         spheres;
+    uint32_t n_quads;           const rt_quad*           quads;
+    uint32_t n_triangles;       const rt_triangle*       triangles;
+    uint32_t n_infinite_planes; const rt_infinite_plane* infinite_planes;
+    uint32_t n_xy_planes;       const rt_axis_plane*     xy_planes;
+    uint32_t n_xz_planes;       const rt_axis_plane*     xz_planes;
+    uint32_t n_yz_planes;       const rt_axis_plane*     yz_planes;
+    uint32_t n_disks;           const rt_disk*           disks;
+    uint32_t n_boxes;           const rt_box*            boxes;
+    uint32_t n_capsules;        const rt_capsule*        capsules;
+    uint32_t n_cylinders;       const rt_cylinder*       cylinders;
+    uint32_t n_media;           const rt_medium*         media;
+    uint32_t n_materials;       const rt_material*       materials;
+    uint32_t n_textures;        const rt_texture*        textures;
+    uint32_t n_lights;          const rt_light*          lights;
+} rt_scene_desc;
+
+/* RenderOptions (Ararem.RayTracer.Core/RenderOptions.cs:11-19) minus what stays host-side
+ * (ConcurrencyLevel, Passes/InfinitePasses: the caller loops over rt_render_passes). */
+typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61; only NONE is rendered today */
+    RT_VIS_NONE = 0
+} rt_debug_vis;
+
+typedef struct rt_render_opts {
+    uint32_t struct_size;            /* sizeof(rt_render_opts) */
+    uint32_t width, height;          /* RenderWidth, RenderHeight (>= 1) */
+    float    k_min, k_max;           /* KMin (0.001), KMax (+inf) */
+    uint32_t max_bounce_depth;       /* MaxBounceDepth (10) */
+    uint32_t light_sample_count_hint;/* LightSampleCountHint (2), >= 1 */
+    uint32_t debug_visualisation;    /* rt_debug_vis */
+    uint64_t seed;                   /* key of the counter RNG that replaces Random.Shared (RandUtils.cs:17) */
+    uint32_t passes_per_batch;       /* passes traced per wavefront batch; 0 = library default */
+    int32_t  device;                 /* HIP device ordinal, -1 = current device */
+    void*    stream;                 /* hipStream_t to enqueue on, NULL = a stream owned by the library */
+    float*   accum_device;           /* optional caller-owned DEVICE buffer of width*height*3 floats (zeroed by the
+                                        caller) that receives the colour sums, e.g. a buffer a collective reduces;
+                                        NULL = owned by the library */
+} rt_render_opts;
+
+/* RenderStats (Ararem.RayTracer.Core/RenderStats.cs:12-93), field for field, plus counters the
+ * reference does not keep (shadow rays are not counted by RenderJob.cs:575). */
+#define RT_DEPTH_HIST_SIZE 64
+typedef struct rt_stats {
+    uint64_t pixels_rendered;        /* RenderJob.cs:108 */
+    uint64_t passes_rendered;        /* :120 */
+    uint64_t material_scatter_count; /* :439 */
+    uint64_t material_absorbed_count;/* :431 */
+    uint64_t aabb_misses;            /* BinaryBvhNode.cs:18, SingleObjectBvhNode.cs:15 (device BVH topology differs) */
+    uint64_t hittable_misses;        /* SingleObjectBvhNode.cs:28 */
+    uint64_t hittable_intersections; /* SingleObjectBvhNode.cs:23 */
+    uint64_t sky_rays;               /* RenderJob.cs:447 */
+    uint64_t bounce_limit_exceeded;  /* :418 */
+    uint64_t ray_count;              /* :583  closest-hit rays */
+    uint64_t shadow_rays;            /* AnyIntersectionFast calls (:575) */
+    uint64_t node_visits;            /* V: box tests during closest-hit traversal */
+    uint64_t prim_tests;             /* T: primitive tests during closest-hit traversal */
+    uint64_t shadow_node_visits;     /* V for any-hit traversal */
+    uint64_t shadow_prim_tests;      /* T for any-hit traversal */
+    uint64_t ray_depth_counts[RT_DEPTH_HIST_SIZE]; /* RenderStats.RayDepthCounts (:458); depths >= 63 land in [63] */
+} rt_stats;
+
+typedef struct rt_ray {              /* Ray.cs:14-26; direction is used as given (callers normalise) */
+    float origin[3];
+    float direction[3];
+} rt_ray;
+
+typedef struct rt_hit {              /* the HitRecord fields parity checks compare (HitRecord.cs:19-20) */
+    float    k;                      /* HitRecord.K; NaN-free; undefined when object == RT_NO_HIT */
+    uint32_t object;                 /* index into objects, RT_NO_HIT on a miss */
+    uint32_t material;
+    float    normal[3];
+    float    uv[2];
+    float    world_point[3];
+    uint32_t outside_face;
+} rt_hit;
+#define RT_NO_HIT 0xFFFFFFFFu
+
+/* ---------------- entry points ---------------- */
+
+int rt_version(void);                               /* RT_ABI_VERSION of the built library */
+const char* rt_last_error(void);
+int rt_device_count(int* n);
+
+/* Flattened Scene (Scene.cs:9) -> device tables + BVH (replaces BvhTree ctor, BvhTree.cs:22-136). */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+
+/* RenderJob ctor (RenderJob.cs:34-62): allocates the colour-sum and sample-count state. */
+int rt_render_create(rt_scene* scene, const rt_render_opts* opts, rt_render** out);
+int rt_render_destroy(rt_render* render);
+
+/* RenderInternal's pass loop body (RenderJob.cs:92-122) for passes first_pass, first_pass+pass_stride, ...
+ * (n_passes of them). pass_stride > 1 is how a caller shards passes over devices (pass p goes to
+ * device p mod G). Blocking. */
+int rt_render_passes(rt_render* render, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride);
+
+/* UpdateBuffers' resolve (RenderJob.cs:646-654): avg -> Clamp01 -> Sqrt -> (byte)(255*c); row 0 = top. */
+int rt_render_read_rgb24(rt_render* render, uint8_t* dst /* width*height*3 */);
+/* rawColourBuffer / sampleCountBuffer (RenderJob.cs:669-672), image-row order (row 0 = top). */
+int rt_render_read_accum(rt_render* render, float* rgb_sum /* width*height*3 */, uint32_t* sample_count /* 1 value */);
+/* Resolve an externally combined sum (e.g. after an RCCL reduce into accum_device) with the given count. */
+int rt_render_resolve_device(rt_render* render, const float* accum_device, uint32_t sample_count, uint8_t* dst_host);
+int rt_render_stats(rt_render* render, rt_stats* out);
+
+/* Parity hooks: RenderJob.TryFindClosestHit (RenderJob.cs:581-617) and AnyIntersectionFast (:575)
+ * on caller-supplied rays. Ray i uses RNG key (seed, pixel=i, pass=0, depth=0) where an
+ * intersector draws random numbers (ConstantDensityMedium.cs:56,63). */
+int rt_trace_closest(rt_scene* scene, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits);
+int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* k_min, const float* k_max, uint64_t n, uint8_t* occluded);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

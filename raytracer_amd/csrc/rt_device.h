@@ -1,0 +1,785 @@
+// rt_device.h — device-side data layout, float math with the reference's operation order, the counter
+// RNG, ray/primitive intersectors, materials, lights and skyboxes for the gfx950 trace kernels.
+//
+// Arithmetic contract: IEEE binary32, one rounding per C# operator (the library is built with
+// -ffp-contract=off and correctly rounded divide/sqrt), operands in the order the reference writes
+// them, so K and the hit/miss decisions are reproducible bit for bit against a CPU restatement.
+// Reference paths are relative to the reference root (Core/ = Ararem.RayTracer.Core/, Impl/ = Ararem.RayTracer.Impl/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rt_hip.h"
+
+#define RT_FN __device__ __forceinline__
+
+namespace rtd {
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float E_F  = 2.71828182845904523536f;
+
+// ------------------------------------------------------------------------------------------------
+// Vector3 (System.Numerics) in registers
+// ------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+RT_FN f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_FN f3 splat(float a) { return mk3(a, a, a); }
+RT_FN f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_FN f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_FN f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_FN f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_FN f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_FN f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_FN f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+RT_FN f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_FN float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_FN f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_FN float length_sq(f3 a) { return dot(a, a); }
+RT_FN float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_FN f3 normalize(f3 a) { return a / length(a); }
+RT_FN float distance_sq(f3 a, f3 b) { f3 d = a - b; return dot(d, d); }
+RT_FN float distance(f3 a, f3 b) { return sqrtf(distance_sq(a, b)); }
+RT_FN f3 lerp3(f3 a, f3 b, float t) { return (a * (1.0f - t)) + (b * t); }
+RT_FN f3 reflect(f3 v, f3 n) { float d = dot(v, n); return v - (n * (2.0f * d)); }
+RT_FN float lerpf(float a, float b, float t) { return a + (t * (b - a)); }
+// MathF.Max / MathF.Min (NaN-propagating)
+RT_FN float maxf_net(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b); }
+RT_FN float minf_net(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b); }
+RT_FN bool is_nan(float a) { return a != a; }
+RT_FN bool is_inf(float a) { return __builtin_isinf(a); }
+RT_FN f3 point_at(f3 o, f3 d, float k) { return o + (k * d); }                      // Core/Ray.cs:22
+
+// ------------------------------------------------------------------------------------------------
+// Counter RNG replacing Random.Shared (Core/RandUtils.cs:17): Philox4x32-10 keyed by
+// (seed, pixel, pass, depth, slot, sub).  Results do not depend on traversal order, batch size or the
+// device a pass is rendered on.
+// ------------------------------------------------------------------------------------------------
+enum : uint32_t { SLOT_CAMERA = 0, SLOT_MEDIUM = 1, SLOT_SCATTER = 2, SLOT_LIGHT = 16, SLOT_LIGHT_RAW = 2048 + 16 };
+
+struct RngKey { uint32_t k0, k1, pixel, pass_lo; };
+
+RT_FN RngKey make_key(uint64_t seed, uint32_t pixel, uint64_t pass) {
+    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(pass >> 32); k.pixel = pixel; k.pass_lo = (uint32_t)pass; return k;
+}
+RT_FN float u01(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }      // Random.NextSingle(): 24 bits in [0,1)
+RT_FN float4 rng_draw(const RngKey& key, uint32_t depth, uint32_t slot, uint32_t sub) {
+    uint32_t c0 = key.pixel, c1 = key.pass_lo, c2 = (depth << 16) | slot, c3 = sub;
+    uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_float4(u01(c0), u01(c1), u01(c2), u01(c3));
+}
+RT_FN float plus_minus_one(float u) { return (u * 2) - 1; }                           // RandUtils.cs:29
+RT_FN f3 on_unit_sphere(float a, float b, float c) {                                   // RandUtils.cs:33-37 (normalised cube sample, biased as in the reference)
+    return normalize(mk3(plus_minus_one(a), plus_minus_one(b), plus_minus_one(c)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene tables in HBM.  Records are float4-aligned so one or two 16-B loads fetch a primitive.
+// ------------------------------------------------------------------------------------------------
+// BVH2 node, 64 B: both children's boxes + both child codes -> one 64-B line per visit.
+//   q0 = (minA.x minA.y minA.z maxA.x)  q1 = (maxA.y maxA.z minB.x minB.y)  q2 = (minB.z maxB.x maxB.y maxB.z)
+//   q3 = (childA, childB, -, -) as int bits: >= 0 inner node index, < 0 leaf holding object ~code, CHILD_EMPTY = none.
+// Leaves hold exactly one object and the leaf's box is that object's Hittable.BoundingVolume, so testing it
+// is the reference's SingleObjectBvhNode box test (Core/Acceleration/SingleObjectBvhNode.cs:12-16).
+struct Node { float4 q0, q1, q2; int4 q3; };
+constexpr int CHILD_EMPTY = (int)0x80000000;
+
+constexpr uint32_t OBJ_TYPE_SHIFT = 28;
+constexpr uint32_t OBJ_INDEX_MASK = (1u << OBJ_TYPE_SHIFT) - 1;
+
+struct SceneDev {
+    const Node*    nodes;        uint32_t n_nodes;
+    const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
+    const uint32_t* obj_material;
+    uint32_t n_objects;
+    const uint32_t* unbounded;   uint32_t n_unbounded;   // objects with a non-finite AABB (InfinitePlane.cs:28), tested for every ray
+    const uint32_t* media;       uint32_t n_media;       // ConstantDensityMedium objects, tested last
+    const float4* spheres;       // 1 x float4 : centre.xyz, radius
+    const float4* quads;         // 4 x float4 : origin.xyz,- | normal.xyz,- | inv_col1 | inv_col2   (triangles share the layout)
+    const float4* triangles;
+    const float4* inf_planes;    // 2 x float4 : point.xyz, negPointDotNormal | normal.xyz, -
+    const float4* axis_planes[3];// 2 x float4 : a_lo a_hi b_lo b_hi | c - - -       [0]=XY [1]=XZ [2]=YZ
+    const float4* disks;         // 4 x float4 : centre.xyz, radius | normal.xyz, negCentreDotNorm | inv_col1 | inv_col2
+    const float4* boxes;         // 6 x float4 : world_to_box[12] | box_to_world_rows[9], pad
+    const float4* capsules;      // 4 x float4 : p1.xyz, radius | p2.xyz, - | uvm[0..3] | uvm[4..7] ; (5th) uvm[8]
+    const float4* cylinders;     // 2 x float4 : p1.xyz, radius | p2.xyz, -
+    const rt_medium* media_rec;
+    const rt_material* materials;
+    const rt_texture* textures;
+    const rt_light* lights;      uint32_t n_lights;
+    rt_camera camera;
+    rt_skybox skybox;
+};
+
+struct Ray { f3 o, d; };
+
+// ------------------------------------------------------------------------------------------------
+// AxisAlignedBoundingBox.Hit, Core/Acceleration/AxisAlignedBoundingBox.cs:63-95.
+// The reference folds kMin/kMax through the three axes with `?:` selects and fails when kMax <= kMin after
+// any axis; because the running kMin only grows and kMax only shrinks this equals the single final test.
+// slab() returns the entry bound (kMin folded in) and the exit bound WITHOUT kMax, so the caller can apply
+// the current kMax at the time of use:  hit <=> !(sel_min(exit, kMax) <= entry).
+// ------------------------------------------------------------------------------------------------
+RT_FN void slab(f3 bmin, f3 bmax, f3 o, f3 invD, float kMin, float& entry, float& exit_) {
+    float t0 = (bmin.x - o.x) * invD.x, t1 = (bmax.x - o.x) * invD.x;
+    if (invD.x < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    float lo = t0 > kMin ? t0 : kMin;
+    float hi = t1;
+    t0 = (bmin.y - o.y) * invD.y; t1 = (bmax.y - o.y) * invD.y;
+    if (invD.y < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    lo = t0 > lo ? t0 : lo;
+    hi = is_nan(hi) ? t1 : (t1 < hi ? t1 : hi);
+    t0 = (bmin.z - o.z) * invD.z; t1 = (bmax.z - o.z) * invD.z;
+    if (invD.z < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    lo = t0 > lo ? t0 : lo;
+    hi = is_nan(hi) ? t1 : (t1 < hi ? t1 : hi);
+    entry = lo; exit_ = hi;
+}
+RT_FN bool slab_hit(float entry, float exit_, float kMax) {
+    float hi = exit_ < kMax ? exit_ : kMax;     // a NaN exit (every axis degenerate) leaves kMax, as the reference's selects do
+    return !(hi <= entry);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Intersectors.  try_* = Hittable.TryHit's decision and K; fast_* = Hittable.FastTryHit.
+// ------------------------------------------------------------------------------------------------
+// Sphere.cs:35-57 / :99-121
+RT_FN bool try_sphere(float4 s, Ray r, float kMin, float kMax, float& k) {
+    f3 oc = r.o - mk3(s.x, s.y, s.z);
+    float a = length_sq(r.d);
+    float halfB = dot(oc, r.d);
+    float c = length_sq(oc) - (s.w * s.w);
+    float disc = (halfB * halfB) - (a * c);
+    if (disc < 0) return false;
+    float sqrtD = sqrtf(disc);
+    float root = (-halfB - sqrtD) / a;
+    if ((root < kMin) || (kMax < root) || is_nan(root)) {
+        root = (-halfB + sqrtD) / a;
+        if ((root < kMin) || (kMax < root) || is_nan(root)) return false;
+    }
+    k = root;
+    return true;
+}
+
+// Quad.cs:82-115 ; Triangle (NEW) replaces the [0,1]^2 test with u>=0, v>=0, u+v<=1
+template <bool TRI>
+RT_FN bool try_quad(const float4* q, Ray r, float kMin, float kMax, float& k, float& u, float& v, float& nd) {
+    float4 q0 = q[0], q1 = q[1];
+    f3 origin = mk3(q0.x, q0.y, q0.z), normal = mk3(q1.x, q1.y, q1.z);
+    nd = dot(normal, r.d);
+    if (fabsf(nd) <= 0.001f) return false;
+    float t = -dot(normal, r.o - origin) / nd;
+    if ((t < kMin) || (t > kMax)) return false;
+    f3 lp = point_at(r.o, r.d, t) - origin;
+    float4 c1 = q[2], c2 = q[3];
+    u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
+    v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
+    if (TRI) { if (!(u >= 0) || !(v >= 0) || !(u + v <= 1)) return false; }
+    else     { if (u < 0 || u > 1 || is_nan(u) || v < 0 || v > 1 || is_nan(v)) return false; }
+    k = t;
+    return true;
+}
+
+// InfinitePlane.cs:37-55 (TryHit) — a NaN t passes the range test there and is turned into a miss by the
+// validator (Core/RenderJob.cs:609-614); :63-82 (FastTryHit) rejects NaN through its >=,<= form.
+RT_FN bool try_inf_plane(const float4* p, Ray r, float kMin, float kMax, float& k, float& nd) {
+    float4 p0 = p[0], p1 = p[1];
+    f3 normal = mk3(p1.x, p1.y, p1.z);
+    nd = dot(r.d, normal);
+    if (fabsf(nd) <= 0.001f) return false;
+    float t = -(dot(r.o, normal) + p0.w) / nd;
+    if ((t < kMin) || (t > kMax)) return false;
+    if (is_nan(t)) return false;
+    k = t;
+    return true;
+}
+
+// XYPlane.cs:53-67, XZPlane.cs:53-66, YZPlane.cs:50-63.  axis: 0 = XY, 1 = XZ, 2 = YZ
+RT_FN bool axis_plane_core(const float4* p, int axis, Ray r, float kMin, float kMax, float& k, float& a, float& b) {
+    float4 p0 = p[0]; float C = p[1].x;
+    float oC = axis == 0 ? r.o.z : axis == 1 ? r.o.y : r.o.x;
+    float dC = axis == 0 ? r.d.z : axis == 1 ? r.d.y : r.d.x;
+    float t = (C - oC) / dC;
+    if ((dC == 0.0f) || is_nan(t)) return false;
+    if ((t < kMin) || (t > kMax)) return false;
+    f3 wp = point_at(r.o, r.d, t);
+    a = axis == 2 ? wp.y : wp.x;
+    b = axis == 0 ? wp.y : wp.z;
+    k = t;
+    (void)p0;
+    return true;
+}
+RT_FN bool try_axis_plane(const float4* p, int axis, Ray r, float kMin, float kMax, float& k) {
+    float a, b;
+    if (!axis_plane_core(p, axis, r, kMin, kMax, k, a, b)) return false;
+    float4 p0 = p[0];
+    if ((a < p0.x) || (a > p0.y) || (b < p0.z) || (b > p0.w)) return false;
+    return true;
+}
+RT_FN bool fast_axis_plane(const float4* p, int axis, Ray r, float kMin, float kMax) {
+    float k, a, b;
+    if (!axis_plane_core(p, axis, r, kMin, kMax, k, a, b)) return false;
+    float4 p0 = p[0];
+    if (axis == 2) return (a >= p0.x) && (a <= p0.y) && (b >= p0.z) && (b <= p0.w);     // YZPlane.cs:89
+    return !(a < p0.x) && !(a > p0.y) && !(b < p0.z) && !(b > p0.w);                   // XYPlane.cs:118-121, XZPlane.cs:91
+}
+
+// Disk.cs:58-81 / :101-123
+RT_FN bool try_disk(const float4* d, Ray r, float kMin, float kMax, float& k, float& nd, bool fast) {
+    float4 d0 = d[0], d1 = d[1];
+    f3 centre = mk3(d0.x, d0.y, d0.z), normal = mk3(d1.x, d1.y, d1.z);
+    nd = dot(r.d, normal);
+    if (fabsf(nd) <= 0.001f) return false;
+    float t = -(dot(r.o, normal) + d1.w) / nd;
+    if ((t < kMin) || (t > kMax)) return false;
+    f3 wp = point_at(r.o, r.d, t);
+    float ds = distance_sq(centre, wp), r2 = d0.w * d0.w;
+    if (fast) { if (!(ds <= r2)) return false; } else { if (ds > r2) return false; }
+    k = t;
+    return true;
+}
+
+// Box.cs:122-145 (TryHit: Transform / TransformNormal) and :191-216 (FastTryHit: Vector4.Transform, w = 0 / 1)
+struct BoxSolve { f3 t1, s; };
+RT_FN bool box_core(const float4* b, Ray r, float kMin, float kMax, bool fast, float& k, BoxSolve& bs) {
+    float4 m0 = b[0], m1 = b[1], m2 = b[2];   // M11 M12 M13 M21 | M22 M23 M31 M32 | M33 M41 M42 M43
+    float M11 = m0.x, M12 = m0.y, M13 = m0.z, M21 = m0.w, M22 = m1.x, M23 = m1.y, M31 = m1.z, M32 = m1.w, M33 = m2.x, M41 = m2.y, M42 = m2.z, M43 = m2.w;
+    f3 rd, ro;
+    if (fast) {
+        rd = mk3((r.d.x * M11) + (r.d.y * M21) + (r.d.z * M31) + (0.0f * M41), (r.d.x * M12) + (r.d.y * M22) + (r.d.z * M32) + (0.0f * M42), (r.d.x * M13) + (r.d.y * M23) + (r.d.z * M33) + (0.0f * M43));
+        ro = mk3((r.o.x * M11) + (r.o.y * M21) + (r.o.z * M31) + (1.0f * M41), (r.o.x * M12) + (r.o.y * M22) + (r.o.z * M32) + (1.0f * M42), (r.o.x * M13) + (r.o.y * M23) + (r.o.z * M33) + (1.0f * M43));
+    } else {
+        rd = mk3((r.d.x * M11) + (r.d.y * M21) + (r.d.z * M31), (r.d.x * M12) + (r.d.y * M22) + (r.d.z * M32), (r.d.x * M13) + (r.d.y * M23) + (r.d.z * M33));
+        ro = mk3((r.o.x * M11) + (r.o.y * M21) + (r.o.z * M31) + M41, (r.o.x * M12) + (r.o.y * M22) + (r.o.z * M32) + M42, (r.o.x * M13) + (r.o.y * M23) + (r.o.z * M33) + M43);
+    }
+    f3 m = splat(1.0f) / rd;
+    if (is_nan(m.x) || is_nan(m.y) || is_nan(m.z) || is_inf(m.x) || is_inf(m.y) || is_inf(m.z)) return false;
+    f3 s = mk3(rd.x < 0.0f ? 1.0f : -1.0f, rd.y < 0.0f ? 1.0f : -1.0f, rd.z < 0.0f ? 1.0f : -1.0f);
+    f3 t1 = m * (-ro + (s / 2.0f));
+    f3 t2 = m * (-ro - (s / 2.0f));
+    float kNear = maxf_net(maxf_net(t1.x, t1.y), t1.z);
+    float kFar = minf_net(minf_net(t2.x, t2.y), t2.z);
+    if ((kNear > kFar) || (kFar < 0.0f)) return false;
+    float kk = kNear;
+    if ((kk < kMin) || (kMax < kk)) {
+        kk = kFar;
+        if ((kk < kMin) || (kMax < kk)) return false;
+    }
+    if (is_nan(kk)) return false;
+    k = kk; bs.t1 = t1; bs.s = s;
+    return true;
+}
+
+// Capsule.cs:77-112 / :147-182.  ba, baba, r2, r2*baba are the constructor's cached products (:51-54).
+RT_FN float capsule_k(f3 P1, f3 P2, float radius, Ray r) {
+    f3 ba = P2 - P1;
+    float baba = dot(ba, ba), r2 = radius * radius, r2baba = r2 * baba;
+    float k = -1.0f;
+    f3 oa = r.o - P1;
+    float bard = dot(ba, r.d), baoa = dot(ba, oa), rdoa = dot(r.d, oa), oaoa = dot(oa, oa);
+    float a = baba - (bard * bard);
+    float b = (baba * rdoa) - (baoa * bard);
+    float c = (baba * oaoa) - (baoa * baoa) - r2baba;
+    float h = (b * b) - (a * c);
+    if (h >= 0.0f) {
+        float t = (-b - sqrtf(h)) / a;
+        float y = baoa + (t * bard);
+        if ((y > 0.0f) && (y < baba)) k = t;
+        else {
+            f3 oc = y <= 0.0f ? oa : r.o - P2;
+            b = dot(r.d, oc);
+            c = dot(oc, oc) - r2;
+            h = (b * b) - c;
+            if (h > 0.0f) k = -b - sqrtf(h);
+        }
+    }
+    return k;
+}
+RT_FN bool try_capsule(const float4* c, Ray r, float kMin, float kMax, float& k, bool fast) {
+    float4 c0 = c[0], c1 = c[1];
+    float kk = capsule_k(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), c0.w, r);
+    if (fast) { if (!((kk != -1.0f) && (kk >= kMin) && (kk <= kMax))) return false; }
+    else      { if ((kk == -1.0f) || (kk < kMin) || (kk > kMax)) return false; if (is_nan(kk)) return false; /* validator, RenderJob.cs:609 */ }
+    k = kk;
+    return true;
+}
+
+// Cylinder.cs:55-98 / :109-142
+RT_FN bool try_cylinder(const float4* c, Ray r, float kMin, float kMax, float& k, f3& normal, bool fast) {
+    float4 c0 = c[0], c1 = c[1];
+    f3 P1 = mk3(c0.x, c0.y, c0.z), P2 = mk3(c1.x, c1.y, c1.z);
+    float radius = c0.w;
+    f3 ba = P2 - P1;
+    float baba = dot(ba, ba), r2baba = radius * radius * baba;
+    f3 oc = r.o - P1;
+    float bard = dot(ba, r.d), baoc = dot(ba, oc);
+    float k2 = baba - (bard * bard);
+    float k1 = (baba * dot(oc, r.d)) - (baoc * bard);
+    float k0 = (baba * dot(oc, oc)) - (baoc * baoc) - r2baba;
+    float h = (k1 * k1) - (k2 * k0);
+    if (h < 0.0f) return false;
+    h = sqrtf(h);
+    float kk = (-k1 - h) / k2;
+    float y = baoc + (kk * bard);
+    if ((y > 0.0f) && (y < baba)) {
+        normal = ((oc + (kk * r.d)) - ((ba * y) / baba)) / radius;
+    } else {
+        kk = ((y < 0.0f ? 0.0f : baba) - baoc) / bard;
+        if (fabsf(k1 + (k2 * kk)) < h) {
+            float sg = y > 0 ? 1.0f : (y < 0 ? -1.0f : 0.0f);
+            normal = (ba * sg) / baba;
+        } else return false;
+    }
+    if (fast) return (kk != -1.0f) && (kk >= kMin) && (kk <= kMax);
+    if ((kk == -1.0f) || !(kk >= kMin) || !(kk <= kMax)) return false;
+    k = kk;
+    return true;
+}
+
+// One object, TryHit semantics.  aux carries ShaderData for media (HitRecord.ShaderData).
+RT_FN bool try_object_solid(const SceneDev& sc, uint32_t type, uint32_t idx, Ray r, float kMin, float kMax, float& k) {
+    float u, v, nd; f3 n; BoxSolve bs;
+    switch (type) {
+        case RT_HIT_SPHERE:         return try_sphere(sc.spheres[idx], r, kMin, kMax, k);
+        case RT_HIT_TRIANGLE:       return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
+        case RT_HIT_QUAD:           return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
+        case RT_HIT_INFINITE_PLANE: return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd);
+        case RT_HIT_XY_PLANE:       return try_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax, k);
+        case RT_HIT_XZ_PLANE:       return try_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax, k);
+        case RT_HIT_YZ_PLANE:       return try_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax, k);
+        case RT_HIT_DISK:           return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, false);
+        case RT_HIT_BOX:            return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, false, k, bs);
+        case RT_HIT_CAPSULE:        return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, false);
+        case RT_HIT_CYLINDER:       return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, false);
+        default: return false;
+    }
+}
+// FastTryHit semantics
+RT_FN bool fast_object_solid(const SceneDev& sc, uint32_t type, uint32_t idx, Ray r, float kMin, float kMax) {
+    float k, u, v, nd; f3 n; BoxSolve bs;
+    switch (type) {
+        case RT_HIT_SPHERE:         return try_sphere(sc.spheres[idx], r, kMin, kMax, k);
+        case RT_HIT_TRIANGLE:       return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
+        case RT_HIT_QUAD:           return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
+        case RT_HIT_INFINITE_PLANE: return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd);
+        case RT_HIT_XY_PLANE:       return fast_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax);
+        case RT_HIT_XZ_PLANE:       return fast_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax);
+        case RT_HIT_YZ_PLANE:       return fast_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax);
+        case RT_HIT_DISK:           return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, true);
+        case RT_HIT_BOX:            return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, true, k, bs);
+        case RT_HIT_CAPSULE:        return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, true);
+        case RT_HIT_CYLINDER:       return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, true);
+        default: return false;
+    }
+}
+
+// ConstantDensityMedium.TryHit, ConstantDensityMedium.cs:46-68.  K = entry.K + dist, ShaderData = dist.
+RT_FN bool try_medium(const SceneDev& sc, uint32_t midx, uint32_t self_obj, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, float& k, float& aux) {
+    rt_medium m = sc.media_rec[midx];
+    float kEntry, kExit;
+    if (!try_object_solid(sc, m.boundary_type, m.boundary_index, r, kMin, kMax, kEntry)) return false;
+    if (!try_object_solid(sc, m.boundary_type, m.boundary_index, r, kEntry + 0.001f, kMax, kExit)) return false;
+    float between = kExit - kEntry;
+    float4 u = rng_draw(key, depth, SLOT_MEDIUM, self_obj);
+    float dist = m.neg_inv_density * logf(u.x);
+    if (dist > between) return false;
+    k = kEntry + dist; aux = dist;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Closest hit / any hit over the whole scene.  `stack` is this lane's LDS column: entry i lives at
+// stack[i * stride] so that the 64 lanes of a wave hit 64 different banks.
+// Result rule: smallest K wins; on an exact tie the larger object index wins (the reference returns
+// whichever its implementation-defined tree visits last, Core/Acceleration/BinaryBvhNode.cs:28-30).
+// ------------------------------------------------------------------------------------------------
+struct Closest { float k; uint32_t obj; float aux; };
+struct TravCount { uint32_t nodes, prims; };
+
+RT_FN void consider(Closest& best, float k, uint32_t obj, float aux) {
+    if (best.obj != RT_NO_HIT && k == best.k && best.obj > obj) return;
+    best.k = k; best.obj = obj; best.aux = aux;
+}
+
+RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(r.o.z) || is_nan(r.d.x) || is_nan(r.d.y) || is_nan(r.d.z); }
+
+RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, int* stack, int stride, TravCount& cnt) {
+    Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
+    if (ray_has_nan(r)) return best;
+    for (uint32_t i = 0; i < sc.n_unbounded; i++) {
+        uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
+        float k; cnt.prims++;
+        if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+    }
+    if (sc.n_nodes) {
+        f3 invD = splat(1.0f) / r.d;
+        int sp = 0, node = 0;
+        for (;;) {
+            const Node* np = sc.nodes + node;
+            float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int4 q3 = np->q3;
+            cnt.nodes += 2;
+            float enA, exA, enB, exB;
+            slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), r.o, invD, kMin, enA, exA);
+            slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), r.o, invD, kMin, enB, exB);
+            int cA = q3.x, cB = q3.y;
+            bool hA = (cA != CHILD_EMPTY) && slab_hit(enA, exA, best.k);
+            bool hB = (cB != CHILD_EMPTY) && slab_hit(enB, exB, best.k);
+            // order: nearer entry first (affects only the amount of work, not the result)
+            if (hA && hB && enB < enA) { int t = cA; cA = cB; cB = t; float e = enA; enA = enB; enB = e; e = exA; exA = exB; exB = e; }
+            else if (!hA && hB) { cA = cB; enA = enB; exA = exB; hA = true; hB = false; }
+            int next = -1;
+            if (hA) {
+                if (cA < 0) {
+                    uint32_t obj = (uint32_t)~cA, code = sc.obj_code[obj]; float k; cnt.prims++;
+                    if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                } else next = cA;
+            }
+            if (hB) {
+                if (cB < 0) {
+                    if (slab_hit(enB, exB, best.k)) {      // leaf box test with the kMax current at the time, as the reference's recursion does
+                        uint32_t obj = (uint32_t)~cB, code = sc.obj_code[obj]; float k; cnt.prims++;
+                        if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                    }
+                } else if (next < 0) next = cB;
+                else { stack[sp * stride] = cB; sp++; }
+            }
+            if (next >= 0) { node = next; continue; }
+            if (sp == 0) break;
+            sp--; node = stack[sp * stride];
+        }
+    }
+    for (uint32_t i = 0; i < sc.n_media; i++) {
+        uint32_t obj = sc.media[i], code = sc.obj_code[obj];
+        float k, aux; cnt.prims++;
+        // SingleObjectBvhNode box test (the medium's BoundingVolume is its boundary's, ConstantDensityMedium.cs:80) is implied:
+        // the boundary intersector only returns points inside that box.
+        if (try_medium(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+    }
+    // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
+    if (best.obj != RT_NO_HIT && !((best.k >= kMin) && (best.k <= kMax))) best.obj = RT_NO_HIT;
+    return best;
+}
+
+// RenderJob.AnyIntersectionFast, Core/RenderJob.cs:575.  The reference scans every object's FastTryHit; culling by
+// conservative boxes returns the same boolean.
+RT_FN bool any_hit(const SceneDev& sc, Ray r, float kMin, float kMax, int* stack, int stride, TravCount& cnt) {
+    for (uint32_t i = 0; i < sc.n_unbounded; i++) {
+        uint32_t code = sc.obj_code[sc.unbounded[i]]; cnt.prims++;
+        if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
+    }
+    for (uint32_t i = 0; i < sc.n_media; i++) {
+        rt_medium m = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; cnt.prims++;
+        if (fast_object_solid(sc, m.boundary_type, m.boundary_index, r, kMin, kMax)) return true;      // ConstantDensityMedium.cs:77
+    }
+    if (!sc.n_nodes) return false;
+    f3 invD = splat(1.0f) / r.d;
+    int sp = 0, node = 0;
+    for (;;) {
+        const Node* np = sc.nodes + node;
+        float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int4 q3 = np->q3;
+        cnt.nodes += 2;
+        float enA, exA, enB, exB;
+        slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), r.o, invD, kMin, enA, exA);
+        slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), r.o, invD, kMin, enB, exB);
+        int cA = q3.x, cB = q3.y;
+        // any-hit boxes use a closed interval (exit >= entry) so a hit exactly on a box face is never culled
+        float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
+        bool hA = (cA != CHILD_EMPTY) && !(hiA < enA);
+        bool hB = (cB != CHILD_EMPTY) && !(hiB < enB);
+        int next = -1;
+        if (hA) {
+            if (cA < 0) {
+                uint32_t code = sc.obj_code[(uint32_t)~cA]; cnt.prims++;
+                if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
+            } else next = cA;
+        }
+        if (hB) {
+            if (cB < 0) {
+                uint32_t code = sc.obj_code[(uint32_t)~cB]; cnt.prims++;
+                if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
+            } else if (next < 0) next = cB;
+            else { stack[sp * stride] = cB; sp++; }
+        }
+        if (next >= 0) { node = next; continue; }
+        if (sp == 0) break;
+        sp--; node = stack[sp * stride];
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HitRecord reconstruction for the winning object (the rest of each TryHit body).
+// ------------------------------------------------------------------------------------------------
+struct HitRec { f3 wp, n; float k, u, v, shader; uint32_t obj, mat; bool outside; };
+
+RT_FN void sphere_uv(f3 p, float& u, float& v) {                                       // Sphere.cs:78-93
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + PI_F;
+    u = phi / (2 * PI_F);
+    v = theta / PI_F;
+}
+
+template <bool WANT_UV>
+RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& key, uint32_t depth) {
+    HitRec h; h.k = c.k; h.obj = c.obj; h.mat = sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
+    uint32_t code = sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
+    h.wp = point_at(r.o, r.d, c.k);
+    h.n = mk3(0, 0, 0);
+    switch (type) {
+        case RT_HIT_SPHERE: {                                                            // Sphere.cs:59-70
+            float4 s = sc.spheres[idx];
+            f3 outN = normalize(h.wp - mk3(s.x, s.y, s.z));
+            bool inside = dot(r.d, outN) > 0.0f;
+            h.n = inside ? -outN : outN; h.outside = !inside;
+            if (WANT_UV) sphere_uv(outN, h.u, h.v);
+        } break;
+        case RT_HIT_QUAD: case RT_HIT_TRIANGLE: {                                        // Quad.cs:100-119
+            const float4* q = (type == RT_HIT_QUAD ? sc.quads : sc.triangles) + 4 * idx;
+            float4 q0 = q[0], q1 = q[1];
+            h.n = mk3(q1.x, q1.y, q1.z);
+            h.outside = dot(h.n, r.d) < 0;
+            if (WANT_UV) {
+                f3 lp = h.wp - mk3(q0.x, q0.y, q0.z); float4 c1 = q[2], c2 = q[3];
+                h.u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
+                h.v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
+            }
+        } break;
+        case RT_HIT_INFINITE_PLANE: {                                                    // InfinitePlane.cs:55-60
+            float4 p1 = sc.inf_planes[2 * idx + 1];
+            h.n = mk3(p1.x, p1.y, p1.z);
+            h.outside = dot(r.d, h.n) < 0;
+        } break;
+        case RT_HIT_XY_PLANE: case RT_HIT_XZ_PLANE: case RT_HIT_YZ_PLANE: {              // XYPlane.cs:69-101
+            int axis = type - RT_HIT_XY_PLANE;
+            const float4* p = sc.axis_planes[axis] + 2 * idx;
+            float4 p0 = p[0]; float C = p[1].x;
+            float oC = axis == 0 ? r.o.z : axis == 1 ? r.o.y : r.o.x;
+            f3 unit = axis == 0 ? mk3(0, 0, 1) : axis == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0);
+            h.n = oC < C ? -unit : unit;
+            if (WANT_UV) {
+                float a = axis == 2 ? h.wp.y : h.wp.x, b = axis == 0 ? h.wp.y : h.wp.z;
+                h.u = (a - p0.x) / (p0.y - p0.x); h.v = (b - p0.z) / (p0.w - p0.z);
+            }
+        } break;
+        case RT_HIT_DISK: {                                                              // Disk.cs:83-97
+            const float4* d = sc.disks + 4 * idx;
+            float4 d0 = d[0], d1 = d[1];
+            h.n = mk3(d1.x, d1.y, d1.z);
+            h.outside = dot(r.d, h.n) < 0;
+            if (WANT_UV) {
+                f3 lp = h.wp - mk3(d0.x, d0.y, d0.z); float4 c1 = d[2], c2 = d[3];
+                float u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
+                float v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
+                if (u < 0 || u > 1 || is_nan(u) || v < 0 || v > 1 || is_nan(v)) {
+                    u = (u > 0.0f) ? u : 0.0f; u = (u < 1.0f) ? u : 1.0f;
+                    v = (v > 0.0f) ? v : 0.0f; v = (v < 1.0f) ? v : 1.0f;
+                }
+                h.u = u; h.v = v;
+            }
+        } break;
+        case RT_HIT_BOX: {                                                               // Box.cs:147-182
+            const float4* b = sc.boxes + 6 * idx;
+            float k; BoxSolve bs;
+            box_core(b, r, c.k, c.k, false, k, bs);     // same t1/s as the accepted test; the range only selects near/far
+            float4 r0 = b[3], r1 = b[4], r2 = b[5];     // rows: r0.xyz | r0.w r1.x r1.y | r1.z r1.w r2.x
+            f3 nrm;
+            if ((bs.t1.x > bs.t1.y) && (bs.t1.x > bs.t1.z)) nrm = mk3(r0.x, r0.y, r0.z) * bs.s.x;
+            else if (bs.t1.y > bs.t1.z) nrm = mk3(r0.w, r1.x, r1.y) * bs.s.y;
+            else nrm = mk3(r1.z, r1.w, r2.x) * bs.s.z;
+            h.n = normalize(nrm);
+            h.outside = dot(r.d, nrm) < 0.0f;
+        } break;
+        case RT_HIT_CAPSULE: {                                                           // Capsule.cs:114-140, CapNormal :186-191
+            const float4* cp = sc.capsules + 5 * idx;
+            float4 c0 = cp[0], c1 = cp[1];
+            f3 P1 = mk3(c0.x, c0.y, c0.z), P2 = mk3(c1.x, c1.y, c1.z); float radius = c0.w;
+            f3 ba = P2 - P1; float baba = dot(ba, ba);
+            f3 pa = h.wp - P1;
+            float hh = dot(pa, ba) / baba; hh = hh < 0.0f ? 0.0f : (hh > 1.0f ? 1.0f : hh);
+            h.n = (pa - (hh * ba)) / radius;
+            h.outside = !(dot(r.d, h.n) > 0.0f);
+            if (WANT_UV) {
+                float4 m0 = cp[2], m1 = cp[3]; float m8 = cp[4].x;
+                f3 q = mk3((pa.x * m0.x) + (pa.y * m0.w) + (pa.z * m1.z) + 0.0f, (pa.x * m0.y) + (pa.y * m1.x) + (pa.z * m1.w) + 0.0f, (pa.x * m0.z) + (pa.y * m1.y) + (pa.z * m8) + 0.0f);
+                float rawU = atan2f(q.y, q.x);
+                h.u = (rawU + PI_F) / 6.2831855f;
+                float lo = -radius, hi = distance(P1, P2) + radius;
+                h.v = (q.z - lo) / (hi - lo);
+            }
+        } break;
+        case RT_HIT_CYLINDER: {                                                          // Cylinder.cs:100-104
+            float k; f3 nrm = mk3(0, 0, 0);
+            try_cylinder(sc.cylinders + 2 * idx, r, c.k, c.k, k, nrm, false);
+            h.n = nrm; h.outside = !(dot(r.d, nrm) > 0.0f);
+        } break;
+        case RT_HIT_MEDIUM: {                                                            // ConstantDensityMedium.cs:61-67
+            float4 u = rng_draw(key, depth, SLOT_MEDIUM, c.obj);
+            h.wp = point_at(r.o, r.d, c.aux);         // sic: measured from the ray origin
+            h.n = on_unit_sphere(u.y, u.z, u.w);
+            h.shader = c.aux; h.outside = true;
+        } break;
+        default: break;
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Textures, skyboxes
+// ------------------------------------------------------------------------------------------------
+struct col3 { float r, g, b; };
+RT_FN col3 mkc(float r, float g, float b) { col3 c; c.r = r; c.g = g; c.b = b; return c; }
+RT_FN col3 operator+(col3 a, col3 b) { return mkc(a.r + b.r, a.g + b.g, a.b + b.b); }
+RT_FN col3 operator*(col3 a, col3 b) { return mkc(a.r * b.r, a.g * b.g, a.b * b.b); }
+RT_FN col3 operator*(col3 a, float s) { return mkc(a.r * s, a.g * s, a.b * s); }
+RT_FN col3 operator/(col3 a, float s) { return mkc(a.r / s, a.g / s, a.b / s); }
+
+// MarbleTexture's noise: SharpNoise's gradient table is not part of the reference tree (parity unpinned);
+// a libnoise-style gradient noise over hashed gradients, 5 octaves, lacunarity 3, persistence .5, linear interpolation.
+RT_FN uint32_t hash3(int32_t x, int32_t y, int32_t z, int32_t seed) {
+    uint32_t h = (uint32_t)x * 1619u + (uint32_t)y * 31337u + (uint32_t)z * 6971u + (uint32_t)seed * 1013u;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+RT_FN float grad_noise(float fx, float fy, float fz, int32_t ix, int32_t iy, int32_t iz, int32_t seed) {
+    uint32_t h = hash3(ix, iy, iz, seed);
+    float gx = (float)((int)(h & 1023u) - 512) * (1.0f / 512.0f);
+    float gy = (float)((int)((h >> 10) & 1023u) - 512) * (1.0f / 512.0f);
+    float gz = (float)((int)((h >> 20) & 1023u) - 512) * (1.0f / 512.0f);
+    float dx = fx - (float)ix, dy = fy - (float)iy, dz = fz - (float)iz;
+    return ((gx * dx) + (gy * dy) + (gz * dz)) * 1.2f;
+}
+RT_FN float coherent_noise(float x, float y, float z, int32_t seed) {
+    float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+    int32_t x0 = (int32_t)flx, y0 = (int32_t)fly, z0 = (int32_t)flz;
+    int32_t x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    float xs = x - flx, ys = y - fly, zs = z - flz;
+    float n0 = grad_noise(x, y, z, x0, y0, z0, seed), n1 = grad_noise(x, y, z, x1, y0, z0, seed);
+    float ix0 = lerpf(n0, n1, xs);
+    n0 = grad_noise(x, y, z, x0, y1, z0, seed); n1 = grad_noise(x, y, z, x1, y1, z0, seed);
+    float ix1 = lerpf(n0, n1, xs);
+    float iy0 = lerpf(ix0, ix1, ys);
+    n0 = grad_noise(x, y, z, x0, y0, z1, seed); n1 = grad_noise(x, y, z, x1, y0, z1, seed);
+    ix0 = lerpf(n0, n1, xs);
+    n0 = grad_noise(x, y, z, x0, y1, z1, seed); n1 = grad_noise(x, y, z, x1, y1, z1, seed);
+    ix1 = lerpf(n0, n1, xs);
+    float iy1 = lerpf(ix0, ix1, ys);
+    return lerpf(iy0, iy1, zs);
+}
+RT_FN float marble_noise(float x, float y, float z) {
+    float value = 0.0f, persistence = 1.0f;
+    for (int o = 0; o < 5; o++) {
+        value = value + (coherent_noise(x, y, z, o) * persistence);
+        x = x * 3.0f; y = y * 3.0f; z = z * 3.0f;
+        persistence = persistence * 0.5f;
+    }
+    return value;
+}
+
+RT_FN col3 texture_colour(const SceneDev& sc, uint32_t tex, f3 wp) {
+    const rt_texture* t = sc.textures + tex;
+    if (t->type == RT_TEX_SOLID) return mkc(t->f[0], t->f[1], t->f[2]);                 // SolidColourTexture.cs:14
+    float scale = t->f[0], noiseScale = t->f[1], noiseStrength = t->f[2], dropoff = t->f[3];   // MarbleTexture.cs:38-48
+    float x = wp.x / scale, y = wp.y / scale, z = wp.z / scale;
+    float tt = x + y + z;
+    tt += marble_noise(x / noiseScale, y / noiseScale, z / noiseScale) * noiseStrength;
+    float val = sinf(tt);
+    val = (0.5f * val) + 0.5f;
+    val = powf(val, dropoff);
+    return (mkc(0, 0, 0) * (1.0f - val)) + (mkc(1, 1, 0.95f) * val);                    // Colour.Lerp, Core/Colour.cs:214
+}
+
+RT_FN col3 sky_colour(const SceneDev& sc, f3 dir) {
+    if (sc.skybox.type == RT_SKY_SINGLE_COLOUR) return mkc(sc.skybox.colour[0], sc.skybox.colour[1], sc.skybox.colour[2]);
+    float t = 0.5f * (dir.y + 1);                                                        // DefaultSkyBox.cs:12-13
+    return mkc((1 - t) + (0.5f * t), (1 - t) + (0.7f * t), (1 - t) + (1.0f * t));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lights
+// ------------------------------------------------------------------------------------------------
+struct ShadowRay { Ray r; float kMin, kMax; };
+
+RT_FN ShadowRay default_shadow_ray(f3 hitPos, f3 lightPos) {                             // SimpleLightBase.cs:42-51
+    ShadowRay s; s.r.o = hitPos; s.r.d = normalize(lightPos - hitPos);                   // Ray.FromPoints -> ctor normalises
+    s.kMin = 0.01f; s.kMax = distance(hitPos, lightPos) - 0.01f;
+    return s;
+}
+RT_FN float attenuation(const rt_light* l, float x) {                                    // SimpleLightBase.cs:55-77
+    switch (l->atten_kind) {
+        case RT_ATTEN_CONSTANT: return l->atten_p[0];
+        case RT_ATTEN_LINEAR: return 1 - x;
+        case RT_ATTEN_POWER: return powf(1 - x, l->atten_p[0]);
+        case RT_ATTEN_POWER_STAY_HIGH: return 1 - powf(x, l->atten_p[0]);
+        case RT_ATTEN_LOGISTIC: return 1.0f / (1 + powf(E_F, l->atten_p[1] * (x - l->atten_p[0])));
+        case RT_ATTEN_LOGISTIC_LKX: return l->atten_p[0] / (1.0f + powf(E_F, -l->atten_p[1] * (x - l->atten_p[2])));
+        default: return powf(E_F, l->atten_p[0] * -x);
+    }
+}
+// GetShadowRayForHit: PointLight.cs:7, DiffuseSphereLight.cs:85-139, DiffuseShapedLight.cs:67-103
+RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f3 normal, const RngKey& key, uint32_t depth, uint32_t slotBase, uint32_t sub) {
+    f3 pos = mk3(l->position[0], l->position[1], l->position[2]);
+    if (l->type == RT_LIGHT_POINT) return default_shadow_ray(wp, pos);
+    if (l->type == RT_LIGHT_DIFFUSE_SPHERE) {
+        float R = l->diffusion_radius;
+        if (distance(wp, pos) <= R * 1.01f) {
+            for (uint32_t i = 0; i < 1000; i++) {
+                float4 u = rng_draw(key, depth, slotBase + i, sub);
+                f3 randDir = on_unit_sphere(u.x, u.y, u.z);
+                if (dot(randDir, normal) < 0) randDir = -randDir;
+                f3 oc = wp - pos;
+                float a = length_sq(randDir);
+                float halfB = dot(oc, randDir);
+                float c = length_sq(oc) - (R * R);
+                float disc = (halfB * halfB) - (a * c);
+                if (disc < 0) continue;
+                float sqrtD = sqrtf(disc);
+                float k = (-halfB - sqrtD) / a;
+                if (is_nan(k)) { k = (-halfB + sqrtD) / a; if (is_nan(k)) continue; }
+                ShadowRay s; s.r.o = wp; s.r.d = normalize(randDir); s.kMin = 0.001f; s.kMax = k;
+                return s;
+            }
+            return default_shadow_ray(wp, pos);
+        }
+        float4 u = rng_draw(key, depth, slotBase, sub);
+        f3 randDir = on_unit_sphere(u.x, u.y, u.z);
+        if (dot(randDir, normalize(wp - pos)) < 0) randDir = -randDir;
+        return default_shadow_ray(wp, pos + (randDir * R));
+    }
+    // DiffuseShapedLight
+    f3 mn = mk3(l->shape_aabb_min[0], l->shape_aabb_min[1], l->shape_aabb_min[2]), mx = mk3(l->shape_aabb_max[0], l->shape_aabb_max[1], l->shape_aabb_max[2]);
+    for (uint32_t i = 0; i < 1000; i++) {
+        float4 u = rng_draw(key, depth, slotBase + i, sub);
+        f3 p2 = mk3(lerpf(mn.x, mx.x, u.x), lerpf(mn.y, mx.y, u.y), lerpf(mn.z, mx.z, u.z));
+        Ray ry; ry.o = wp; ry.d = normalize(p2 - wp);
+        float k;
+        if (try_object_solid(sc, l->shape_type, l->shape_index, ry, 0.0001f, __builtin_inff(), k)) {
+            ShadowRay s; s.r = ry; s.kMin = 0.001f; s.kMax = k - 0.001f; return s;
+        }
+    }
+    ShadowRay s; s.r.o = wp; s.r.d = normalize(splat(1.0f)); s.kMin = 0.0f; s.kMax = __builtin_inff();
+    return s;
+}
+
+// Camera.GetRay, Core/Camera.cs:35-42 with RandUtils.RandomInUnitCircle, Core/RandUtils.cs:53-59
+RT_FN Ray camera_ray(const rt_camera& cam, float u, float v, float thetaU, float rU) {
+    float theta = 0 + (((2 * PI_F) - 0) * thetaU);
+    float rr = sqrtf(rU);
+    float sx = sinf(theta), cy = cosf(theta);
+    float randX = (rr * sx) * cam.lens_radius, randY = (rr * cy) * cam.lens_radius;
+    f3 U = mk3(cam.u[0], cam.u[1], cam.u[2]), V = mk3(cam.v[0], cam.v[1], cam.v[2]);
+    f3 offset = (U * randX) + (V * randY);
+    f3 origin = mk3(cam.look_from[0], cam.look_from[1], cam.look_from[2]) + offset;
+    f3 llc = mk3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+    f3 hor = mk3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]), ver = mk3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    f3 direction = (llc + (u * hor) + (v * ver)) - origin;
+    Ray r; r.o = origin; r.d = normalize(normalize(direction));      // GetRay normalises, then the Ray ctor normalises again (Core/Ray.cs:17)
+    return r;
+}
+
+} // namespace rtd

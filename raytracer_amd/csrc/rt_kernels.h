@@ -1,0 +1,346 @@
+// rt_kernels.h — the wavefront trace kernels (gfx950).
+//
+// One batch = P paths = (pixels) x (passes in the batch).  Path state lives in SoA arrays indexed by path id;
+// queues hold the ids of the paths still alive at the current bounce.  Per bounce:
+//   k_closest : queue -> closest hit (BVH traversal, per-lane stack in LDS)            RenderJob.cs:581-617
+//   k_shade   : hit/miss -> sky, scatter, affine colour terms, shadow requests,
+//               survivors compacted into the next queue with a wave ballot             RenderJob.cs:413-451, materials
+//   k_shadow  : one thread per shaded hit, LightSampleCountHint x |lights| any-hit rays Material.cs:30-45, SimpleLightBase.cs:22-40
+// then k_accumulate adds the finished radiance into the image sums in pass order       RenderJob.cs:626-647
+// and k_resolve makes RGB24                                                             RenderJob.cs:646-654.
+//
+// The reference walks the hits backwards and lets each material transform the "future" colour
+// (RenderJob.cs:461-487).  Every builtin CalculateColour is affine in that colour, final = a*future + c, so
+// the kernels carry a throughput T and add T*c as they go: L = sum_k T_k c_k + T_n * terminal, T_{k+1} = T_k a_k.
+#pragma once
+#include "rt_device.h"
+
+namespace rtd {
+
+constexpr int BLOCK = 256;
+
+enum StatSlot : int {
+    ST_RAYS = 0, ST_SHADOW_RAYS, ST_NODES, ST_PRIMS, ST_SH_NODES, ST_SH_PRIMS, ST_SKY, ST_LIMIT, ST_SCATTER, ST_ABSORBED, ST_SAMPLES,
+    ST_DEPTH0, ST_COUNT = ST_DEPTH0 + RT_DEPTH_HIST_SIZE
+};
+
+struct RenderDev {
+    float* ray[6];            // origin xyz, direction xyz
+    float* thr[3];            // T
+    float* rad[3];            // L
+    float* hit_k; uint32_t* hit_obj; float* hit_aux;
+    uint32_t* prev_mat; uint32_t* first_mat;
+    uint32_t* queue[2];       // ping-pong path-id queues
+    uint32_t* squeue;         // shadow requests (path ids)
+    float* sh_wp[3]; float* sh_n[3]; float* sh_w[3]; float* sh_in[3];   // shadow request payload, by path id
+    uint32_t* qcount;         // [max_depth + 2] alive paths per bounce
+    uint32_t* sqcount;        // [max_depth + 2] shadow requests per bounce
+    unsigned long long* stats;// [ST_COUNT]
+    uint32_t width, height, n_pixels;
+    uint32_t n_paths;         // pixels * passes in this batch
+    uint64_t first_pass; uint32_t pass_stride;    // pass of path p = first_pass + (p / n_pixels) * pass_stride
+    uint64_t seed;
+    float k_min, k_max;
+    uint32_t max_depth, light_samples;
+};
+
+RT_FN uint32_t lane_id() { return threadIdx.x & 63u; }
+
+RT_FN unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+RT_FN void stat_add(unsigned long long* stats, int slot, unsigned long long v) {
+    v = wave_sum(v);
+    if (lane_id() == 0 && v) atomicAdd(stats + slot, v);
+}
+
+RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
+    uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
+    return make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
+}
+RT_FN Ray load_ray(const RenderDev& rd, uint32_t id) {
+    Ray r; r.o = mk3(rd.ray[0][id], rd.ray[1][id], rd.ray[2][id]); r.d = mk3(rd.ray[3][id], rd.ray[4][id], rd.ray[5][id]); return r;
+}
+RT_FN void store_ray(const RenderDev& rd, uint32_t id, Ray r) {
+    rd.ray[0][id] = r.o.x; rd.ray[1][id] = r.o.y; rd.ray[2][id] = r.o.z; rd.ray[3][id] = r.d.x; rd.ray[4][id] = r.d.y; rd.ray[5][id] = r.d.z;
+}
+
+// RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay
+__global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
+    for (uint32_t id = blockIdx.x * BLOCK + threadIdx.x; id < rd.n_paths; id += gridDim.x * BLOCK) {
+        uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
+        uint32_t x = pix % rd.width, y = pix / rd.width;                                   // Decompress2DIndex, MathUtils.cs:38-43
+        RngKey key = make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
+        float4 u = rng_draw(key, 0, SLOT_CAMERA, 0);
+        float s = (float)x, t = (float)y;
+        s += plus_minus_one(u.x) * 0.5f;
+        t += plus_minus_one(u.y) * 0.5f;
+        Ray r = camera_ray(sc.camera, s / (float)rd.width, t / (float)rd.height, u.z, u.w);
+        store_ray(rd, id, r);
+        rd.thr[0][id] = 1.0f; rd.thr[1][id] = 1.0f; rd.thr[2][id] = 1.0f;
+        rd.rad[0][id] = 0.0f; rd.rad[1][id] = 0.0f; rd.rad[2][id] = 0.0f;
+        rd.prev_mat[id] = RT_NO_HIT; rd.first_mat[id] = RT_NO_HIT;
+        rd.queue[0][id] = id;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = rd.n_paths;
+}
+
+extern __shared__ int lds_stack[];   // [stack_depth][BLOCK]
+
+__global__ void __launch_bounds__(BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+    const uint32_t n = rd.qcount[depth];
+    const uint32_t* q = rd.queue[depth & 1];
+    unsigned long long rays = 0, nodes = 0, prims = 0;
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+        uint32_t id = q[j];
+        Ray r = load_ray(rd, id);
+        RngKey key = path_key(rd, id);
+        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        Closest c = closest_hit(sc, r, rd.k_min, rd.k_max, key, depth, lds_stack + threadIdx.x, BLOCK, cnt);
+        rd.hit_k[id] = c.k; rd.hit_obj[id] = c.obj; rd.hit_aux[id] = c.aux;
+        rays++; nodes += cnt.nodes; prims += cnt.prims;
+    }
+    stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
+}
+
+// wave-level order-preserving append: one atomic per wave
+RT_FN uint32_t wave_append(uint32_t* counter, bool want) {
+    unsigned long long m = __ballot(want);
+    uint32_t base = 0;
+    if (m) {
+        uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+        base = __shfl(base, (int)leader, 64);
+    }
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane_id()) - 1ull));
+}
+
+__global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
+    const uint32_t n = rd.qcount[depth];
+    const uint32_t* q = rd.queue[depth & 1];
+    uint32_t* qn = rd.queue[(depth + 1) & 1];
+    unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0;
+    const uint32_t n_round = (n + 63u) & ~63u;       // whole waves iterate together so ballots see every lane
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n_round; j += gridDim.x * BLOCK) {
+        bool active = j < n, survive = false, shadow = false;
+        uint32_t id = 0;
+        if (active) {
+            id = q[j];
+            Ray r = load_ray(rd, id);
+            col3 T = mkc(rd.thr[0][id], rd.thr[1][id], rd.thr[2][id]);
+            col3 L = mkc(rd.rad[0][id], rd.rad[1][id], rd.rad[2][id]);
+            Closest c; c.k = rd.hit_k[id]; c.obj = rd.hit_obj[id]; c.aux = rd.hit_aux[id];
+            if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450
+                L = L + (T * sky_colour(sc, r.d));
+                sky++; samples++;
+                if (depth > 0) hist_miss++;                                              // RenderJob.cs:458: maxDepthReached = depth - 1
+            } else {
+                RngKey key = path_key(rd, id);
+                HitRec h = finalize_hit<false>(sc, r, c, key, depth);
+                const rt_material* m = sc.materials + h.mat;
+                uint32_t prev = rd.prev_mat[id], first = rd.first_mat[id];
+                float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
+                Ray nr; nr.o = h.wp;
+                col3 a = mkc(1, 1, 1);        // multiplier of the future colour
+                col3 W = mkc(0, 0, 0);        // weight of the light sum
+                bool lights = false;
+                switch (m->type) {
+                    case RT_MAT_STANDARD: {                                              // StandardMaterial.cs:45-60
+                        f3 diffuse = on_unit_sphere(u.x, u.y, u.z);
+                        if (dot(diffuse, h.n) < 0) diffuse = diffuse * -1.0f;
+                        f3 refl = reflect(r.d, h.n);
+                        nr.d = normalize(normalize(lerp3(refl, diffuse, m->f[0])));
+                        a = texture_colour(sc, m->tex[0], h.wp);
+                        L = L + (T * texture_colour(sc, m->tex[1], h.wp));
+                        W = T * a; lights = true;
+                    } break;
+                    case RT_MAT_PHONG: {                                                 // PhongMaterial.cs:18-76
+                        f3 dir = on_unit_sphere(u.x, u.y, u.z);
+                        if (dot(dir, h.n) < 0) dir = dir * -1.0f;
+                        nr.d = normalize(dir);
+                        col3 spec = mkc(m->f[0], m->f[1], m->f[2]), diff = mkc(m->f[3], m->f[4], m->f[5]), amb = mkc(m->f[6], m->f[7], m->f[8]);
+                        f3 rl = reflect(r.d, -h.n);
+                        float sw = powf(fabsf(dot(r.d, rl)), powf(2.0f, m->f[9]));
+                        L = L + (T * amb);
+                        a = diff + (spec * sw);
+                        W = T; lights = true;
+                        rd.sh_in[0][id] = r.d.x; rd.sh_in[1][id] = r.d.y; rd.sh_in[2][id] = r.d.z;
+                    } break;
+                    case RT_MAT_VOLUMETRIC: {                                            // ConstantDensityMedium.cs:102-129
+                        nr.d = normalize(on_unit_sphere(u.x, u.y, u.z));
+                        float pw = m->f[3] * h.shader;
+                        a = mkc(powf(m->f[0], pw), powf(m->f[1], pw), powf(m->f[2], pw));
+                    } break;
+                    default: {                                                           // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
+                        f3 ud = normalize(r.d);
+                        float cosT = minf_net(dot(-ud, h.n), 1.0f);
+                        float sinT = sqrtf(1.0f - (cosT * cosT));
+                        bool entering = (depth == 0) || (prev != h.mat);
+                        float eta = entering ? 1.0f : m->f[0], etaP = entering ? m->f[0] : 1.0f;
+                        float ratio = eta / etaP;
+                        bool cannot = ratio * sinT > 1.0f;
+                        float r0 = (eta - etaP) / (eta + etaP);
+                        r0 *= r0;
+                        float reflectance = r0 + ((1 - r0) * powf(1 - cosT, 5.0f));
+                        if (reflectance > u.w) cannot = true;
+                        f3 out;
+                        if (cannot) out = reflect(ud, h.n);
+                        else if (!(m->flags & RT_MAT_FLAG_ALTERNATE_REFRACTION)) {
+                            f3 perp = ratio * (ud + (cosT * h.n));
+                            f3 par = -sqrtf(fabsf(1.0f - length_sq(perp))) * h.n;
+                            out = perp + par;
+                        } else {
+                            float nd = dot(h.n, ud);
+                            out = normalize((sqrtf((1 - powf(ratio, 2.0f)) * (1 - powf(nd, 2.0f))) * h.n) + (ratio * (ud - (nd * h.n))));
+                        }
+                        nr.d = normalize(out);
+                        a = texture_colour(sc, m->tex[0], h.wp);
+                        W = T * a; lights = true;
+                        if (m->type == RT_MAT_EMISSIVE_REFRACTIVE) {
+                            bool emit = (m->flags & RT_MAT_FLAG_DIRECT_EMISSION) || !(depth == 0 || (depth == 1 && first == h.mat));
+                            if (emit) L = L + (T * texture_colour(sc, m->tex[1], h.wp));
+                        }
+                    } break;
+                }
+                scat++;                                                                   // RenderJob.cs:439
+                shadow = lights && sc.n_lights > 0;
+                if (shadow) {
+                    rd.sh_wp[0][id] = h.wp.x; rd.sh_wp[1][id] = h.wp.y; rd.sh_wp[2][id] = h.wp.z;
+                    rd.sh_n[0][id] = h.n.x; rd.sh_n[1][id] = h.n.y; rd.sh_n[2][id] = h.n.z;
+                    rd.sh_w[0][id] = W.r; rd.sh_w[1][id] = W.g; rd.sh_w[2][id] = W.b;
+                }
+                T = T * a;
+                if (depth < rd.max_depth) {
+                    survive = true;
+                    store_ray(rd, id, nr);
+                    rd.thr[0][id] = T.r; rd.thr[1][id] = T.g; rd.thr[2][id] = T.b;
+                    rd.prev_mat[id] = h.mat;
+                    if (depth == 0) rd.first_mat[id] = h.mat;
+                } else {                                                                  // RenderJob.cs:416-421: the next depth exceeds the limit, future = NoColour
+                    limit++; samples++;                                                   // maxDepthReached = depth
+                }
+            }
+            rd.rad[0][id] = L.r; rd.rad[1][id] = L.g; rd.rad[2][id] = L.b;
+        }
+        uint32_t pos = wave_append(rd.qcount + depth + 1, survive);
+        if (survive) qn[pos] = id;
+        uint32_t spos = wave_append(rd.sqcount + depth, shadow);
+        if (shadow) rd.squeue[spos] = id;
+    }
+    stat_add(rd.stats, ST_SKY, sky); stat_add(rd.stats, ST_LIMIT, limit); stat_add(rd.stats, ST_SCATTER, scat); stat_add(rd.stats, ST_SAMPLES, samples);
+    if (depth > 0) stat_add(rd.stats, ST_DEPTH0 + (int)min(depth - 1, (uint32_t)RT_DEPTH_HIST_SIZE - 1), hist_miss);
+    stat_add(rd.stats, ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1), limit);
+}
+
+// Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
+__global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+    const uint32_t n = rd.sqcount[depth];
+    unsigned long long rays = 0, nodes = 0, prims = 0;
+    int* stack = lds_stack + threadIdx.x;
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+        uint32_t id = rd.squeue[j];
+        RngKey key = path_key(rd, id);
+        f3 wp = mk3(rd.sh_wp[0][id], rd.sh_wp[1][id], rd.sh_wp[2][id]);
+        f3 nrm = mk3(rd.sh_n[0][id], rd.sh_n[1][id], rd.sh_n[2][id]);
+        col3 W = mkc(rd.sh_w[0][id], rd.sh_w[1][id], rd.sh_w[2][id]);
+        const rt_material* m = sc.materials + sc.obj_material[rd.hit_obj[id]];   // hit_obj still holds this bounce's hit
+        const bool phong = m->type == RT_MAT_PHONG;
+        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0);
+        f3 in = phong ? mk3(rd.sh_in[0][id], rd.sh_in[1][id], rd.sh_in[2][id]) : mk3(0, 0, 0);
+        for (uint32_t s = 0; s < rd.light_samples; s++) {
+            for (uint32_t li = 0; li < sc.n_lights; li++) {
+                const rt_light* l = sc.lights + li;
+                uint32_t sub = s * sc.n_lights + li;
+                ShadowRay sr = light_shadow_ray(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
+                rays++;
+                col3 c = mkc(0, 0, 0);
+                if (!any_hit(sc, sr.r, sr.kMin, sr.kMax, stack, BLOCK, cnt)) {
+                    if (!(sr.kMax > l->cutoff_radius)) {
+                        float scale = attenuation(l, sr.kMax / l->attenuation_radius);
+                        scale = maxf_net(scale, 0);
+                        c = mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
+                    }
+                }
+                if (!phong) sum = sum + c;
+                else {                                                                    // PhongMaterial.cs:42-56
+                    ShadowRay s2 = light_shadow_ray(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
+                    rays++;
+                    col3 c2 = any_hit(sc, s2.r, s2.kMin, s2.kMax, stack, BLOCK, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
+                    f3 rl = reflect(s2.r.d, -nrm);
+                    float sd = fabsf(dot(in, rl));
+                    spec_sum = spec_sum + (c2 * powf(sd, powf(2.0f, m->f[9])));
+                    float dd = fabsf(dot(sr.r.d, nrm));
+                    sum = sum + (c * dd);
+                }
+            }
+        }
+        float S = (float)rd.light_samples;
+        sum = sum / S;
+        col3 add;
+        if (!phong) add = W * sum;
+        else { spec_sum = spec_sum / S; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
+        rd.rad[0][id] += add.r; rd.rad[1][id] += add.g; rd.rad[2][id] += add.b;
+        nodes += cnt.nodes; prims += cnt.prims;
+    }
+    stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
+}
+
+// UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — passes of the batch are added in pass order.
+__global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum, uint32_t n_passes) {
+    for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < rd.n_pixels; pix += gridDim.x * BLOCK) {
+        uint32_t x = pix % rd.width, y = pix / rd.width;
+        uint32_t yy = rd.height - y - 1;
+        float* dst = accum + 3 * ((size_t)x + (size_t)yy * rd.width);
+        float r = dst[0], g = dst[1], b = dst[2];
+        for (uint32_t p = 0; p < n_passes; p++) {
+            size_t id = (size_t)p * rd.n_pixels + pix;
+            r += rd.rad[0][id]; g += rd.rad[1][id]; b += rd.rad[2][id];
+        }
+        dst[0] = r; dst[1] = g; dst[2] = b;
+    }
+}
+
+// RenderJob.cs:646-654 ; Colour.Clamp01 / Sqrt / (Rgb24), Colour.cs:197-234
+__global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t sample_count, size_t n_values, uint8_t* out) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += (size_t)gridDim.x * BLOCK) {
+        float c = accum[i] / (float)(int)sample_count;
+        c = (c > 0.0f) ? c : 0.0f;
+        c = (c < 1.0f) ? c : 1.0f;
+        c = sqrtf(c);
+        out[i] = (uint8_t)(255 * c);
+    }
+}
+
+// Parity hooks: one thread per caller-supplied ray.
+__global__ void __launch_bounds__(BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
+        RngKey key = make_key(seed, (uint32_t)i, 0);
+        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        Closest c = closest_hit(sc, r, kMin, kMax, key, 0, lds_stack + threadIdx.x, BLOCK, cnt);
+        rt_hit h = {};
+        h.object = RT_NO_HIT; h.material = RT_NO_HIT;
+        if (c.obj != RT_NO_HIT) {
+            HitRec hr = finalize_hit<true>(sc, r, c, key, 0);
+            h.k = hr.k; h.object = hr.obj; h.material = hr.mat;
+            h.normal[0] = hr.n.x; h.normal[1] = hr.n.y; h.normal[2] = hr.n.z;
+            h.uv[0] = hr.u; h.uv[1] = hr.v;
+            h.world_point[0] = hr.wp.x; h.world_point[1] = hr.wp.y; h.world_point[2] = hr.wp.z;
+            h.outside_face = hr.outside ? 1u : 0u;
+        }
+        hits[i] = h;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
+        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        occluded[i] = any_hit(sc, r, kMin[i], kMax[i], lds_stack + threadIdx.x, BLOCK, cnt) ? 1 : 0;
+    }
+}
+
+} // namespace rtd

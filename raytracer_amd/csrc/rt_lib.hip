@@ -1,0 +1,471 @@
+// rt_lib.hip — C ABI (include/rt_hip.h) of the gfx950 trace-loop library: scene flattening to device tables,
+// BVH build, wavefront scheduling of the kernels in rt_kernels.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_bvh.h"
+#include "rt_kernels.h"
+
+using namespace rtd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// owns one device allocation
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { if (p) { (void)hipFree(p); p = nullptr; } bytes = n; if (!n) return hipSuccess; return hipMalloc(&p, n); }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+template <class T>
+int upload(DevBuf& b, const std::vector<T>& v) {
+    HIP_TRY(b.alloc(v.size() * sizeof(T)));
+    if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+struct DeviceGuard {      // restore the caller's current device on scope exit
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+inline bool finite3(const float* a) { return std::isfinite(a[0]) && std::isfinite(a[1]) && std::isfinite(a[2]); }
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    SceneDev dev{};
+    uint32_t stack_depth = 1;        // per-lane traversal stack entries
+    uint32_t n_objects = 0, n_lights = 0;
+    int n_cu = 256;
+    DevBuf nodes, obj_code, obj_material, unbounded, media, spheres, quads, triangles, inf_planes, axis[3], disks, boxes, capsules, cylinders,
+           media_rec, materials, textures, lights;
+};
+
+struct rt_render {
+    rt_scene* scene = nullptr;
+    rt_render_opts opts{};
+    RenderDev rd{};
+    uint32_t passes_per_batch = 1;
+    size_t max_paths = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    float* accum = nullptr; bool own_accum = false;
+    uint32_t sample_count = 0;
+    uint64_t passes_rendered = 0;
+    DevBuf f32_pool, u32_pool, counters, stats, accum_buf, rgb;
+    std::vector<unsigned long long> stats_host;
+};
+
+extern "C" {
+
+int rt_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(int* n) {
+    if (!n) return fail(RT_ERR_INVALID_ARG, "rt_device_count: null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return RT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Scene
+// -------------------------------------------------------------------------------------------------
+static int check_prim(const rt_scene_desc* d, uint32_t type, uint32_t index, bool allow_medium) {
+    uint32_t n = 0;
+    switch (type) {
+        case RT_HIT_SPHERE: n = d->n_spheres; break;
+        case RT_HIT_QUAD: n = d->n_quads; break;
+        case RT_HIT_TRIANGLE: n = d->n_triangles; break;
+        case RT_HIT_INFINITE_PLANE: n = d->n_infinite_planes; break;
+        case RT_HIT_XY_PLANE: n = d->n_xy_planes; break;
+        case RT_HIT_XZ_PLANE: n = d->n_xz_planes; break;
+        case RT_HIT_YZ_PLANE: n = d->n_yz_planes; break;
+        case RT_HIT_DISK: n = d->n_disks; break;
+        case RT_HIT_BOX: n = d->n_boxes; break;
+        case RT_HIT_CAPSULE: n = d->n_capsules; break;
+        case RT_HIT_CYLINDER: n = d->n_cylinders; break;
+        case RT_HIT_MEDIUM: if (!allow_medium) return fail(RT_ERR_INVALID_ARG, "a ConstantDensityMedium cannot be used here"); n = d->n_media; break;
+        default: return fail(RT_ERR_UNSUPPORTED, "unknown hittable type %u (user-defined Hittables are rejected, not emulated)", type);
+    }
+    if (index >= n) return fail(RT_ERR_INVALID_ARG, "hittable index %u out of range for type %u (table has %u)", index, type, n);
+    if (index > OBJ_INDEX_MASK) return fail(RT_ERR_TOO_LARGE, "more than 2^28 primitives of one type");
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
+    if (!d || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
+    *out = nullptr;
+    if (d->struct_size != sizeof(rt_scene_desc) || d->abi_version != RT_ABI_VERSION)
+        return fail(RT_ERR_INVALID_ARG, "rt_scene_desc size/version mismatch (got %u/%u, want %zu/%d)", d->struct_size, d->abi_version, sizeof(rt_scene_desc), RT_ABI_VERSION);
+#define NEED(ptr, n) if ((n) && !(ptr)) return fail(RT_ERR_INVALID_ARG, "table %s is null but its count is %u", #ptr, (unsigned)(n))
+    NEED(d->objects, d->n_objects); NEED(d->spheres, d->n_spheres); NEED(d->quads, d->n_quads); NEED(d->triangles, d->n_triangles);
+    NEED(d->infinite_planes, d->n_infinite_planes); NEED(d->xy_planes, d->n_xy_planes); NEED(d->xz_planes, d->n_xz_planes); NEED(d->yz_planes, d->n_yz_planes);
+    NEED(d->disks, d->n_disks); NEED(d->boxes, d->n_boxes); NEED(d->capsules, d->n_capsules); NEED(d->cylinders, d->n_cylinders); NEED(d->media, d->n_media);
+    NEED(d->materials, d->n_materials); NEED(d->textures, d->n_textures); NEED(d->lights, d->n_lights);
+#undef NEED
+    if (d->skybox.type > RT_SKY_SINGLE_COLOUR) return fail(RT_ERR_UNSUPPORTED, "unknown skybox type %u (user-defined SkyBoxes are rejected)", d->skybox.type);
+    for (uint32_t i = 0; i < d->n_textures; i++)
+        if (d->textures[i].type > RT_TEX_MARBLE) return fail(RT_ERR_UNSUPPORTED, "texture %u: unknown type %u (GreyscaleNoise/CustomFunction textures are rejected)", i, d->textures[i].type);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rt_material& m = d->materials[i];
+        if (m.type > RT_MAT_VOLUMETRIC) return fail(RT_ERR_UNSUPPORTED, "material %u: unknown type %u (user-defined Materials are rejected)", i, m.type);
+        uint32_t ntex = m.type == RT_MAT_STANDARD || m.type == RT_MAT_EMISSIVE_REFRACTIVE ? 2 : m.type == RT_MAT_REFRACTIVE ? 1 : 0;
+        for (uint32_t t = 0; t < ntex; t++) if (m.tex[t] >= d->n_textures) return fail(RT_ERR_INVALID_ARG, "material %u: texture index %u out of range", i, m.tex[t]);
+    }
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const rt_light& l = d->lights[i];
+        if (l.type > RT_LIGHT_DIFFUSE_SHAPED) return fail(RT_ERR_UNSUPPORTED, "light %u: unknown type %u (user-defined Lights are rejected)", i, l.type);
+        if (l.atten_kind > RT_ATTEN_EXP_DECAY) return fail(RT_ERR_UNSUPPORTED, "light %u: unknown attenuation kind %u", i, l.atten_kind);
+        if (l.type == RT_LIGHT_DIFFUSE_SHAPED) { int rc = check_prim(d, l.shape_type, l.shape_index, false); if (rc) return rc; }
+    }
+    for (uint32_t i = 0; i < d->n_media; i++) { int rc = check_prim(d, d->media[i].boundary_type, d->media[i].boundary_index, false); if (rc) return rc; }
+
+    std::vector<uint32_t> obj_code(d->n_objects), obj_mat(d->n_objects), unbounded, media;
+    std::vector<rtbvh::Box> boxes; std::vector<uint32_t> box_obj;
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object& o = d->objects[i];
+        int rc = check_prim(d, o.type, o.index, true); if (rc) return rc;
+        if (o.material >= d->n_materials) return fail(RT_ERR_INVALID_ARG, "object %u: material index %u out of range", i, o.material);
+        obj_code[i] = (o.type << OBJ_TYPE_SHIFT) | o.index; obj_mat[i] = o.material;
+        if (o.type == RT_HIT_MEDIUM) { media.push_back(i); continue; }
+        bool nan = false;
+        for (int a = 0; a < 3; a++) nan |= std::isnan(o.aabb_min[a]) || std::isnan(o.aabb_max[a]);
+        if (nan) return fail(RT_ERR_INVALID_ARG, "object %u: NaN in its bounding volume", i);
+        if (!finite3(o.aabb_min) || !finite3(o.aabb_max)) { unbounded.push_back(i); continue; }
+        rtbvh::Box b; for (int a = 0; a < 3; a++) { b.mn[a] = o.aabb_min[a]; b.mx[a] = o.aabb_max[a]; }
+        boxes.push_back(b); box_obj.push_back(i);
+    }
+    rtbvh::BuildResult bvh = rtbvh::build(boxes, box_obj);
+
+    // float4-aligned records
+    auto pack = [](const float* src, size_t n_rec, size_t floats_in, size_t quads_out) {
+        std::vector<float4> v(n_rec * quads_out, make_float4(0, 0, 0, 0));
+        for (size_t r = 0; r < n_rec; r++) memcpy((float*)&v[r * quads_out], src + r * floats_in, floats_in * sizeof(float));
+        return v;
+    };
+    std::vector<float4> spheres = pack((const float*)d->spheres, d->n_spheres, 4, 1);
+    std::vector<float4> quads(d->n_quads * 4), tris(d->n_triangles * 4), planes(d->n_infinite_planes * 2), disks(d->n_disks * 4), caps(d->n_capsules * 5), cyls(d->n_cylinders * 2);
+    for (uint32_t i = 0; i < d->n_quads; i++) {
+        const rt_quad& q = d->quads[i];
+        quads[4 * i + 0] = make_float4(q.origin[0], q.origin[1], q.origin[2], 0); quads[4 * i + 1] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0);
+        quads[4 * i + 2] = make_float4(q.inv_col1[0], q.inv_col1[1], q.inv_col1[2], q.inv_col1[3]); quads[4 * i + 3] = make_float4(q.inv_col2[0], q.inv_col2[1], q.inv_col2[2], q.inv_col2[3]);
+    }
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        const rt_triangle& q = d->triangles[i];
+        tris[4 * i + 0] = make_float4(q.v0[0], q.v0[1], q.v0[2], 0); tris[4 * i + 1] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0);
+        tris[4 * i + 2] = make_float4(q.inv_col1[0], q.inv_col1[1], q.inv_col1[2], q.inv_col1[3]); tris[4 * i + 3] = make_float4(q.inv_col2[0], q.inv_col2[1], q.inv_col2[2], q.inv_col2[3]);
+    }
+    for (uint32_t i = 0; i < d->n_infinite_planes; i++) {
+        const rt_infinite_plane& p = d->infinite_planes[i];
+        planes[2 * i + 0] = make_float4(p.point[0], p.point[1], p.point[2], p.neg_point_dot_normal); planes[2 * i + 1] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0);
+    }
+    std::vector<float4> axis[3];
+    const rt_axis_plane* ap[3] = {d->xy_planes, d->xz_planes, d->yz_planes}; const uint32_t an[3] = {d->n_xy_planes, d->n_xz_planes, d->n_yz_planes};
+    for (int a = 0; a < 3; a++) {
+        axis[a].resize(an[a] * 2);
+        for (uint32_t i = 0; i < an[a]; i++) { axis[a][2 * i] = make_float4(ap[a][i].a_lo, ap[a][i].a_hi, ap[a][i].b_lo, ap[a][i].b_hi); axis[a][2 * i + 1] = make_float4(ap[a][i].c, 0, 0, 0); }
+    }
+    for (uint32_t i = 0; i < d->n_disks; i++) {
+        const rt_disk& k = d->disks[i];
+        disks[4 * i + 0] = make_float4(k.centre[0], k.centre[1], k.centre[2], k.radius); disks[4 * i + 1] = make_float4(k.normal[0], k.normal[1], k.normal[2], k.neg_centre_dot_norm);
+        disks[4 * i + 2] = make_float4(k.inv_col1[0], k.inv_col1[1], k.inv_col1[2], k.inv_col1[3]); disks[4 * i + 3] = make_float4(k.inv_col2[0], k.inv_col2[1], k.inv_col2[2], k.inv_col2[3]);
+    }
+    std::vector<float4> bxs = pack((const float*)d->boxes, d->n_boxes, 21, 6);
+    for (uint32_t i = 0; i < d->n_capsules; i++) {
+        const rt_capsule& c = d->capsules[i];
+        caps[5 * i + 0] = make_float4(c.p1[0], c.p1[1], c.p1[2], c.radius); caps[5 * i + 1] = make_float4(c.p2[0], c.p2[1], c.p2[2], 0);
+        caps[5 * i + 2] = make_float4(c.uv_matrix[0], c.uv_matrix[1], c.uv_matrix[2], c.uv_matrix[3]); caps[5 * i + 3] = make_float4(c.uv_matrix[4], c.uv_matrix[5], c.uv_matrix[6], c.uv_matrix[7]);
+        caps[5 * i + 4] = make_float4(c.uv_matrix[8], 0, 0, 0);
+    }
+    for (uint32_t i = 0; i < d->n_cylinders; i++) {
+        const rt_cylinder& c = d->cylinders[i];
+        cyls[2 * i + 0] = make_float4(c.p1[0], c.p1[1], c.p1[2], c.radius); cyls[2 * i + 1] = make_float4(c.p2[0], c.p2[1], c.p2[2], 0);
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(RT_ERR_NO_DEVICE, "hipGetDevice failed"); }
+    if (device >= ndev) return fail(RT_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
+
+    auto s = std::make_unique<rt_scene>();
+    s->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc;
+    std::vector<Node> nodes(bvh.nodes.size());
+    static_assert(sizeof(Node) == sizeof(rtbvh::HostNode), "node layouts must agree");
+    if (!nodes.empty()) memcpy(nodes.data(), bvh.nodes.data(), nodes.size() * sizeof(Node));
+#define UP(buf, vec) if ((rc = upload(s->buf, vec))) return rc
+    UP(nodes, nodes); UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
+    UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis[0], axis[0]); UP(axis[1], axis[1]); UP(axis[2], axis[2]);
+    UP(disks, disks); UP(boxes, bxs); UP(capsules, caps); UP(cylinders, cyls);
+    std::vector<rt_medium> mrec(d->media, d->media + d->n_media);
+    std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
+    std::vector<rt_texture> texs(d->textures, d->textures + d->n_textures);
+    std::vector<rt_light> lts(d->lights, d->lights + d->n_lights);
+    UP(media_rec, mrec); UP(materials, mats); UP(textures, texs); UP(lights, lts);
+#undef UP
+    SceneDev& sd = s->dev;
+    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)nodes.size();
+    sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>(); sd.n_objects = d->n_objects;
+    sd.unbounded = s->unbounded.as<uint32_t>(); sd.n_unbounded = (uint32_t)unbounded.size();
+    sd.media = s->media.as<uint32_t>(); sd.n_media = (uint32_t)media.size();
+    sd.spheres = s->spheres.as<float4>(); sd.quads = s->quads.as<float4>(); sd.triangles = s->triangles.as<float4>(); sd.inf_planes = s->inf_planes.as<float4>();
+    for (int a = 0; a < 3; a++) sd.axis_planes[a] = s->axis[a].as<float4>();
+    sd.disks = s->disks.as<float4>(); sd.boxes = s->boxes.as<float4>(); sd.capsules = s->capsules.as<float4>(); sd.cylinders = s->cylinders.as<float4>();
+    sd.media_rec = s->media_rec.as<rt_medium>(); sd.materials = s->materials.as<rt_material>(); sd.textures = s->textures.as<rt_texture>();
+    sd.lights = s->lights.as<rt_light>(); sd.n_lights = d->n_lights;
+    sd.camera = d->camera; sd.skybox = d->skybox;
+    s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2);
+    if ((size_t)s->stack_depth * BLOCK * sizeof(int) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "BVH depth %u needs more LDS than one workgroup may use", bvh.max_depth);
+    s->n_objects = d->n_objects; s->n_lights = d->n_lights;
+    *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s) {
+    if (!s) return RT_OK;
+    DeviceGuard guard(s->device);
+    delete s;
+    return RT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Launch helpers
+// -------------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t blocks_per_cu) {
+    uint64_t need = (work + BLOCK - 1) / BLOCK;
+    uint64_t cap = (uint64_t)s->n_cu * blocks_per_cu;
+    return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
+}
+static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * sizeof(int); }
+
+// -------------------------------------------------------------------------------------------------
+// Parity hooks
+// -------------------------------------------------------------------------------------------------
+int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits) {
+    if (!s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_trace_closest: null argument");
+    if (!n) return RT_OK;
+    if (n > (1ull << 32) - 1) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest: at most 2^32-1 rays per call");
+    DeviceGuard guard(s->device);
+    DevBuf dr, dh;
+    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dh.alloc(n * sizeof(rt_hit)));
+    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const float* k_max, uint64_t n, uint8_t* occluded) {
+    if (!s || (n && (!rays || !k_min || !k_max || !occluded))) return fail(RT_ERR_INVALID_ARG, "rt_trace_any: null argument");
+    if (!n) return RT_OK;
+    if (n > (1ull << 32) - 1) return fail(RT_ERR_TOO_LARGE, "rt_trace_any: at most 2^32-1 rays per call");
+    DeviceGuard guard(s->device);
+    DevBuf dr, d0, d1, dout;
+    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(d0.alloc(n * sizeof(float))); HIP_TRY(d1.alloc(n * sizeof(float))); HIP_TRY(dout.alloc(n));
+    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d0.p, k_min, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d1.p, k_max, n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(occluded, dout.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Render job
+// -------------------------------------------------------------------------------------------------
+int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
+    if (!s || !o || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_create: null argument");
+    *out = nullptr;
+    if (o->struct_size != sizeof(rt_render_opts)) return fail(RT_ERR_INVALID_ARG, "rt_render_opts size mismatch (got %u, want %zu)", o->struct_size, sizeof(rt_render_opts));
+    if (o->width < 1 || o->height < 1) return fail(RT_ERR_INVALID_ARG, "Image cannot have a width/height of less than 1 pixel");          // RenderOptions.cs:52,63
+    if (o->k_min < 0 || std::isnan(o->k_min)) return fail(RT_ERR_INVALID_ARG, "KMin cannot have a value of less than 0");                   // :74
+    if (o->k_max < o->k_min || std::isnan(o->k_max)) return fail(RT_ERR_INVALID_ARG, "KMax cannot have a value of less than 0 or less than KMin"); // :86
+    if (o->light_sample_count_hint < 1) return fail(RT_ERR_INVALID_ARG, "Must have at least 1 sample per light");                         // :160
+    if (o->debug_visualisation != RT_VIS_NONE) return fail(RT_ERR_UNSUPPORTED, "debug visualisation %u is not implemented on the device", o->debug_visualisation);
+    if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
+    if (o->device >= 0 && o->device != s->device) return fail(RT_ERR_INVALID_ARG, "render device %d differs from the scene's device %d", o->device, s->device);
+    const uint64_t n_pixels = (uint64_t)o->width * o->height;
+    if (n_pixels > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "more than 2^31 pixels");
+
+    DeviceGuard guard(s->device);
+    auto r = std::make_unique<rt_render>();
+    r->scene = s; r->opts = *o;
+    // paths per batch: enough to keep 256 CUs busy at deep bounces, bounded so the state stays a few GiB
+    const uint64_t target_paths = 16ull << 20;
+    uint32_t ppb = o->passes_per_batch ? o->passes_per_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
+    if (n_pixels * ppb > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^31 paths");
+    r->passes_per_batch = ppb;
+    const size_t P = (size_t)(n_pixels * ppb);
+    r->max_paths = P;
+
+    if (o->stream) r->stream = (hipStream_t)o->stream;
+    else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
+
+    const int n_f32 = 6 + 3 + 3 + 2 + 12;     // ray, thr, rad, hit_k, hit_aux, shadow payload
+    const int n_u32 = 1 + 2 + 2 + 1;          // hit_obj, prev/first mat, 2 queues, shadow queue
+    HIP_TRY(r->f32_pool.alloc(P * n_f32 * sizeof(float)));
+    HIP_TRY(r->u32_pool.alloc(P * n_u32 * sizeof(uint32_t)));
+    const uint32_t n_cnt = o->max_bounce_depth + 2;
+    HIP_TRY(r->counters.alloc(2 * n_cnt * sizeof(uint32_t)));
+    HIP_TRY(r->stats.alloc(ST_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(r->stats.p, 0, r->stats.bytes, r->stream));
+    HIP_TRY(r->rgb.alloc(n_pixels * 3));
+    if (o->accum_device) r->accum = o->accum_device;
+    else {
+        HIP_TRY(r->accum_buf.alloc(n_pixels * 3 * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(r->accum_buf.p, 0, r->accum_buf.bytes, r->stream));
+        r->accum = r->accum_buf.as<float>(); r->own_accum = true;
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+
+    RenderDev& rd = r->rd;
+    float* f = r->f32_pool.as<float>(); uint32_t* u = r->u32_pool.as<uint32_t>();
+    auto nf = [&]() { float* p = f; f += P; return p; };
+    auto nu = [&]() { uint32_t* p = u; u += P; return p; };
+    for (int i = 0; i < 6; i++) rd.ray[i] = nf();
+    for (int i = 0; i < 3; i++) rd.thr[i] = nf();
+    for (int i = 0; i < 3; i++) rd.rad[i] = nf();
+    rd.hit_k = nf(); rd.hit_aux = nf();
+    for (int i = 0; i < 3; i++) rd.sh_wp[i] = nf();
+    for (int i = 0; i < 3; i++) rd.sh_n[i] = nf();
+    for (int i = 0; i < 3; i++) rd.sh_w[i] = nf();
+    for (int i = 0; i < 3; i++) rd.sh_in[i] = nf();
+    rd.hit_obj = nu(); rd.prev_mat = nu(); rd.first_mat = nu(); rd.queue[0] = nu(); rd.queue[1] = nu(); rd.squeue = nu();
+    rd.qcount = r->counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
+    rd.stats = r->stats.as<unsigned long long>();
+    rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
+    rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
+    rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+    r->stats_host.assign(ST_COUNT, 0);
+    *out = r.release();
+    return RT_OK;
+}
+
+int rt_render_destroy(rt_render* r) {
+    if (!r) return RT_OK;
+    DeviceGuard guard(r->scene->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+    return RT_OK;
+}
+
+// One wavefront batch of `np` passes starting at pass `first` (stride `stride`); enqueues only.
+static int enqueue_batch(rt_render* r, uint64_t first, uint32_t np, uint32_t stride) {
+    rt_scene* s = r->scene;
+    RenderDev rd = r->rd;
+    rd.n_paths = rd.n_pixels * np; rd.first_pass = first; rd.pass_stride = stride;
+    hipStream_t st = r->stream;
+    const uint32_t n_cnt = r->opts.max_bounce_depth + 2;
+    HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
+    const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
+    const size_t lds = stack_bytes(s);
+    hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd);
+    for (uint32_t depth = 0; depth <= r->opts.max_bounce_depth; depth++) {
+        hipLaunchKernelGGL(k_closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
+        hipLaunchKernelGGL(k_shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth);
+        if (s->n_lights) hipLaunchKernelGGL(k_shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
+    }
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, rd.n_pixels, 8)), dim3(BLOCK), 0, st, rd, r->accum, np);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride) {
+    if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_passes: null handle");
+    if (pass_stride < 1) pass_stride = 1;
+    DeviceGuard guard(r->scene->device);
+    uint32_t done = 0;
+    while (done < n_passes) {
+        uint32_t np = std::min(r->passes_per_batch, n_passes - done);
+        int rc = enqueue_batch(r, first_pass + (uint64_t)done * pass_stride, np, pass_stride);
+        if (rc) return rc;
+        done += np;
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->sample_count += n_passes; r->passes_rendered += n_passes;
+    return RT_OK;
+}
+
+int rt_render_resolve_device(rt_render* r, const float* accum_device, uint32_t sample_count, uint8_t* dst_host) {
+    if (!r || !accum_device || !dst_host) return fail(RT_ERR_INVALID_ARG, "rt_render_resolve_device: null argument");
+    if (sample_count < 1) return fail(RT_ERR_INVALID_ARG, "rt_render_resolve_device: no samples to resolve");
+    DeviceGuard guard(r->scene->device);
+    const size_t nv = (size_t)r->rd.n_pixels * 3;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(r->scene, nv, 8)), dim3(BLOCK), 0, r->stream, accum_device, sample_count, nv, r->rgb.as<uint8_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst_host, r->rgb.p, nv, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return RT_OK;
+}
+
+int rt_render_read_rgb24(rt_render* r, uint8_t* dst) {
+    if (!r || !dst) return fail(RT_ERR_INVALID_ARG, "rt_render_read_rgb24: null argument");
+    return rt_render_resolve_device(r, r->accum, r->sample_count, dst);
+}
+
+int rt_render_read_accum(rt_render* r, float* rgb_sum, uint32_t* sample_count) {
+    if (!r || !rgb_sum) return fail(RT_ERR_INVALID_ARG, "rt_render_read_accum: null argument");
+    DeviceGuard guard(r->scene->device);
+    HIP_TRY(hipMemcpyAsync(rgb_sum, r->accum, (size_t)r->rd.n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (sample_count) *sample_count = r->sample_count;
+    return RT_OK;
+}
+
+int rt_render_stats(rt_render* r, rt_stats* out) {
+    if (!r || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_stats: null argument");
+    DeviceGuard guard(r->scene->device);
+    HIP_TRY(hipMemcpyAsync(r->stats_host.data(), r->stats.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    const auto& h = r->stats_host;
+    memset(out, 0, sizeof(*out));
+    out->pixels_rendered = h[ST_SAMPLES]; out->passes_rendered = r->passes_rendered;
+    out->material_scatter_count = h[ST_SCATTER]; out->material_absorbed_count = h[ST_ABSORBED];
+    out->sky_rays = h[ST_SKY]; out->bounce_limit_exceeded = h[ST_LIMIT]; out->ray_count = h[ST_RAYS]; out->shadow_rays = h[ST_SHADOW_RAYS];
+    out->node_visits = h[ST_NODES]; out->prim_tests = h[ST_PRIMS]; out->shadow_node_visits = h[ST_SH_NODES]; out->shadow_prim_tests = h[ST_SH_PRIMS];
+    for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) out->ray_depth_counts[i] = h[ST_DEPTH0 + i];
+    return RT_OK;
+}
+
+} // extern "C"
