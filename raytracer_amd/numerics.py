@@ -102,9 +102,11 @@ def matmul4(a, b) -> np.ndarray:
 
 
 def invert4(mat) -> np.ndarray:
-    """Matrix4x4.Invert (cofactor expansion, software path). Raises ArithmeticError when singular."""
-    a, b, c, d = (f32(x) for x in mat[0]); e, f, g, h = (f32(x) for x in mat[1])
-    i, j, k, l = (f32(x) for x in mat[2]); m, n, o, p = (f32(x) for x in mat[3])
+    """Matrix4x4.Invert (cofactor expansion, software path), for one matrix or a stack (..., 4, 4).
+    Raises ArithmeticError when (any matrix is) singular."""
+    mat = np.asarray(mat, dtype=np.float32)
+    a, b, c, d = (mat[..., 0, q] for q in range(4)); e, f, g, h = (mat[..., 1, q] for q in range(4))
+    i, j, k, l = (mat[..., 2, q] for q in range(4)); m, n, o, p = (mat[..., 3, q] for q in range(4))
     kp_lo = k * p - l * o; jp_ln = j * p - l * n; jo_kn = j * o - k * n
     ip_lm = i * p - l * m; io_km = i * o - k * m; in_jm = i * n - j * m
     a11 = +(f * kp_lo - g * jp_ln + h * jo_kn)
@@ -112,27 +114,28 @@ def invert4(mat) -> np.ndarray:
     a13 = +(e * jp_ln - f * ip_lm + h * in_jm)
     a14 = -(e * jo_kn - f * io_km + g * in_jm)
     det = a * a11 + b * a12 + c * a13 + d * a14
-    if abs(det) < np.finfo(np.float32).smallest_subnormal:
+    # MathF.Abs(det) < float.Epsilon (the smallest subnormal); a non-finite determinant is rejected too
+    if np.any(np.abs(det) < np.finfo(np.float32).smallest_subnormal) or not np.all(np.isfinite(det)):
         raise ArithmeticError("matrix is not invertible")
     inv = f32(1.0) / det
-    r = np.zeros((4, 4), dtype=np.float32)
-    r[0, 0] = a11 * inv; r[1, 0] = a12 * inv; r[2, 0] = a13 * inv; r[3, 0] = a14 * inv
-    r[0, 1] = -(b * kp_lo - c * jp_ln + d * jo_kn) * inv
-    r[1, 1] = +(a * kp_lo - c * ip_lm + d * io_km) * inv
-    r[2, 1] = -(a * jp_ln - b * ip_lm + d * in_jm) * inv
-    r[3, 1] = +(a * jo_kn - b * io_km + c * in_jm) * inv
+    r = np.zeros(mat.shape, dtype=np.float32)
+    r[..., 0, 0] = a11 * inv; r[..., 1, 0] = a12 * inv; r[..., 2, 0] = a13 * inv; r[..., 3, 0] = a14 * inv
+    r[..., 0, 1] = -(b * kp_lo - c * jp_ln + d * jo_kn) * inv
+    r[..., 1, 1] = +(a * kp_lo - c * ip_lm + d * io_km) * inv
+    r[..., 2, 1] = -(a * jp_ln - b * ip_lm + d * in_jm) * inv
+    r[..., 3, 1] = +(a * jo_kn - b * io_km + c * in_jm) * inv
     gp_ho = g * p - h * o; fp_hn = f * p - h * n; fo_gn = f * o - g * n
     ep_hm = e * p - h * m; eo_gm = e * o - g * m; en_fm = e * n - f * m
-    r[0, 2] = +(b * gp_ho - c * fp_hn + d * fo_gn) * inv
-    r[1, 2] = -(a * gp_ho - c * ep_hm + d * eo_gm) * inv
-    r[2, 2] = +(a * fp_hn - b * ep_hm + d * en_fm) * inv
-    r[3, 2] = -(a * fo_gn - b * eo_gm + c * en_fm) * inv
+    r[..., 0, 2] = +(b * gp_ho - c * fp_hn + d * fo_gn) * inv
+    r[..., 1, 2] = -(a * gp_ho - c * ep_hm + d * eo_gm) * inv
+    r[..., 2, 2] = +(a * fp_hn - b * ep_hm + d * en_fm) * inv
+    r[..., 3, 2] = -(a * fo_gn - b * eo_gm + c * en_fm) * inv
     gl_hk = g * l - h * k; fl_hj = f * l - h * j; fk_gj = f * k - g * j
     el_hi = e * l - h * i; ek_gi = e * k - g * i; ej_fi = e * j - f * i
-    r[0, 3] = -(b * gl_hk - c * fl_hj + d * fk_gj) * inv
-    r[1, 3] = +(a * gl_hk - c * el_hi + d * ek_gi) * inv
-    r[2, 3] = -(a * fl_hj - b * el_hi + d * ej_fi) * inv
-    r[3, 3] = +(a * fk_gj - b * ek_gi + c * ej_fi) * inv
+    r[..., 0, 3] = -(b * gl_hk - c * fl_hj + d * fk_gj) * inv
+    r[..., 1, 3] = +(a * gl_hk - c * el_hi + d * ek_gi) * inv
+    r[..., 2, 3] = -(a * fl_hj - b * el_hi + d * ej_fi) * inv
+    r[..., 3, 3] = +(a * fk_gj - b * ek_gi + c * ej_fi) * inv
     return r
 
 

@@ -1,0 +1,88 @@
+"""Shared ray-set and scene helpers for the parity tests."""
+import numpy as np
+
+import raytracer_amd as rt
+from raytracer_amd import builtin_scenes as bs
+from raytracer_amd.core import Camera, Colour, Scene, SceneObject
+from raytracer_amd import impl
+
+
+def small_scenes():
+    """name -> Scene factories covering every hittable/material/light/texture/skybox type."""
+    return {
+        "Demo": bs.Demo,
+        "Testing": bs.Testing,
+        "CornellBox": bs.CornellBox,
+        "RgbSpheres": bs.RgbSpheres,
+        "Sphere": bs.SphereScene,
+        "RtInAWeekendCover1": bs.RtInAWeekendCover1,
+        "Zoo": zoo_scene,
+        "MiniMesh": lambda: bs.TriangleMesh(grid=24),
+        "MiniManyLights": lambda: bs.ManySpheresManyLights(n_spheres=2000, n_lights=9),
+        "Empty": empty_scene,
+    }
+
+
+def empty_scene():
+    return Scene("Empty", Camera.Create((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 1.0), [], [], impl.DefaultSkyBox())
+
+
+def zoo_scene():
+    """Every primitive the builtin scenes do not use (Cylinder, Triangle, Phong, DiffuseShapedLight, every attenuation)."""
+    W = Colour.White
+    objs = [
+        SceneObject("cyl", impl.Cylinder((-2, 0, 0), (-2, 2, 0.5), 0.5, Material=impl.PhongMaterial(Shininess=3.0))),
+        SceneObject("tri", impl.Triangle((0, 0, -1), (2, 0, -1), (1, 2, -1.5), Material=impl.StandardMaterial(Colour(.8, .3, .3), .2))),
+        SceneObject("quad", impl.Quad((1, 0, 1), (1, 0, 0), (0, 1, 0.2), Material=impl.StandardMaterial(Colour(.3, .8, .3), impl.MarbleTexture(), .9))),
+        SceneObject("disk", impl.Disk((0, 0.5, 2), (0.2, 1, 0.1), 1.0)),
+        SceneObject("box", impl.Box((2, 0, -3), (3, 1, -2), Material=impl.EmissiveRefractiveMaterial(1.5, W, Colour.Blue * 0.5, False, True))),
+        SceneObject("caps", impl.Capsule((-1, 0.5, -2), (0, 1.0, -2.5), 0.4, Material=impl.RefractiveMaterial(2.4, Colour(.9, .9, 1)))),
+        SceneObject("smoke", impl.ConstantDensityMedium(impl.Sphere((0, 1, 0), 0.8), 1.5, Colour(.5, .5, .5))),
+        SceneObject("xy", impl.XYPlane(-4, 4, 0, 4, -4)),
+        SceneObject("yz", impl.YZPlane(0, 4, -4, 4, -4)),
+        SceneObject("floor", impl.XZPlane(-4, 4, -4, 4, 0)),
+        SceneObject("ground", impl.InfinitePlane((0, -0.5, 0), (0, 2, 0))),
+    ]
+    A = impl.DistanceAttenuation
+    lights = [
+        impl.PointLight(Position=(0, 5, 0), AttenuationRadius=10, DistanceAttenuationFunc=A.Linear(), CutoffRadius=10),
+        impl.PointLight(Position=(3, 3, 3), AttenuationRadius=8, DistanceAttenuationFunc=A.Power(2.0)),
+        impl.PointLight(Position=(-3, 3, 3), AttenuationRadius=8, DistanceAttenuationFunc=A.Power(2.0, True), CutoffRadius=8),
+        impl.DiffuseSphereLight(Position=(0, 3, -3), DiffusionRadius=0.5, AttenuationRadius=8, DistanceAttenuationFunc=A.LogisticsCurve()),
+        impl.DiffuseSphereLight(Position=(0, 1, 0), DiffusionRadius=1.2, AttenuationRadius=4, DistanceAttenuationFunc=A.LogisticsCurveLKX(1.0, -8.0, 0.5)),
+        impl.DiffuseShapedLight(impl.Quad((-1, 3.9, -1), (2, 0, 0), (0, 0, 2)), Position=(0, 3.9, 0), Colour=W * 0.5, AttenuationRadius=6),
+    ]
+    return Scene("Zoo", Camera.Create((0, 2, 7), (0, 1, 0), (0, 1, 0), 50, 16 / 9, 0.01, 7.0), objs, lights, impl.DefaultSkyBox())
+
+
+def scene_bounds(flat):
+    o = np.ctypeslib.as_array(flat.desc.objects, shape=(max(flat.n_objects, 1),)) if flat.n_objects else None
+    if o is None:
+        return np.array([-1, -1, -1], np.float32), np.array([1, 1, 1], np.float32)
+    import ctypes as C
+    raw = np.frombuffer((C.c_char * (flat.n_objects * 36)).from_address(C.addressof(flat.desc.objects.contents)), dtype=np.float32).reshape(-1, 9)
+    mn, mx = raw[:, 3:6], raw[:, 6:9]
+    fin = np.isfinite(mn).all(axis=1) & np.isfinite(mx).all(axis=1)
+    if not fin.any():
+        return np.array([-1, -1, -1], np.float32), np.array([1, 1, 1], np.float32)
+    return mn[fin].min(axis=0), mx[fin].max(axis=0)
+
+
+def camera_rays(scene, width, height, n, rs):
+    """Primary rays through random image points (Camera.GetRay without lens offset)."""
+    cam = scene.Camera
+    u = rs.random(n, dtype=np.float32); v = rs.random(n, dtype=np.float32)
+    o = np.broadcast_to(cam.LookFrom, (n, 3)).astype(np.float32)
+    d = cam.LowerLeftCorner[None, :] + u[:, None] * cam.Horizontal[None, :] + v[:, None] * cam.Vertical[None, :] - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o.copy(), d
+
+
+def secondary_rays(flat, n, rs):
+    """Incoherent rays: random origins inside the (slightly grown) scene bounds, random unit directions."""
+    mn, mx = scene_bounds(flat)
+    c, e = (mn + mx) / 2, np.maximum((mx - mn) / 2, 1e-3) * 1.2
+    o = (c + (rs.random((n, 3), dtype=np.float32) * 2 - 1) * e).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d

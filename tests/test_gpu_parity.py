@@ -1,0 +1,172 @@
+"""GPU parity: the HIP library (through the C ABI) against oracle/ on the same seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY §8d):
+  check 1  fixed ray sets (primary + incoherent secondary): object id, material id, outside-face and any-hit
+           booleans bit-exact; K within 1e-5 relative (observed: bit-equal, both sides use one rounding per operator).
+  check 2  images: linear colour sums per pixel vs the oracle at the same (seed, pixel, pass) RNG keys —
+           mean relative error <= 0.5 % per channel; the RGB24 sky region within 2 LSB.
+"""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import builtin_scenes as bs
+from raytracer_amd.core import RenderOptions
+from raytracer_amd.flatten import flatten_scene
+from oracle import binding as ob
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+NO_HIT = 0xFFFFFFFF
+SCENES = list(helpers.small_scenes())
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sc = helpers.small_scenes()[name]()
+            flat = flatten_scene(sc)
+            cache[name] = (sc, flat, rt.DeviceScene(flat), ob.OracleScene(flat))
+        return cache[name]
+    return get
+
+
+def ray_set(sc, flat, n, seed):
+    rs = np.random.default_rng(seed)
+    o1, d1 = helpers.camera_rays(sc, 64, 64, n, rs)
+    o2, d2 = helpers.secondary_rays(flat, n, rs)
+    return np.concatenate([o1, o2]), np.concatenate([d1, d2])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_closest_hit_parity(pairs, name):
+    sc, flat, dev, orc = pairs(name)
+    o, d = ray_set(sc, flat, 50_000, 11)
+    for kmin, kmax in ((0.001, np.inf), (0.5, 6.0)):
+        g = dev.TraceClosest(o, d, kmin, kmax, seed=99)
+        r = orc.trace_closest(o, d, kmin, kmax, seed=99)
+        assert np.array_equal(g["object"], r["object"]), f"{(g['object'] != r['object']).sum()} hit ids differ"
+        assert np.array_equal(g["material"], r["material"])
+        hit = r["object"] != NO_HIT
+        if name != "Empty":
+            assert hit.sum() > 1000 or kmax < np.inf
+        rel = np.abs(g["k"][hit] - r["k"][hit]) / np.maximum(np.abs(r["k"][hit]), 1e-20)
+        assert rel.max(initial=0) <= 1e-5
+        assert np.array_equal(g["outside_face"][hit], r["outside_face"][hit])
+        assert np.allclose(g["normal"][hit], r["normal"][hit], rtol=0, atol=2e-6)
+        assert np.allclose(g["world_point"][hit], r["world_point"][hit], rtol=1e-6, atol=1e-6)
+        assert np.allclose(g["uv"][hit], r["uv"][hit], rtol=0, atol=2e-6)       # acos/atan2 differ by an ulp between libm and the device library
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_any_hit_parity(pairs, name):
+    sc, flat, dev, orc = pairs(name)
+    o, d = ray_set(sc, flat, 50_000, 12)
+    rs = np.random.default_rng(5)
+    kmin = np.full(len(o), 0.01, np.float32)
+    kmax = rs.uniform(0.1, 30.0, len(o)).astype(np.float32)
+    g = dev.TraceAny(o, d, kmin, kmax)
+    r = orc.trace_any(o, d, kmin, kmax)
+    assert np.array_equal(g, r), f"{(g != r).sum()} any-hit results differ"
+
+
+def test_edge_rays(pairs):
+    sc, flat, dev, orc = pairs("Demo")
+    o = np.array([[np.nan, 0, 0], [0, 1, 0], [0, 1, 0], [0, 5, 0], [0, 5, 0], [0, 1e30, 0]], np.float32)
+    d = np.array([[0, 0, -1], [np.nan, 0, 0], [0, 0, 0], [0, -1, 0], [1, 0, 0], [0, -1, 0]], np.float32)
+    g, r = dev.TraceClosest(o, d), orc.trace_closest(o, d)
+    assert np.array_equal(g["object"], r["object"])
+    assert dev.TraceClosest(np.zeros((0, 3)), np.zeros((0, 3))).shape == (0,)          # empty input
+
+
+@pytest.mark.parametrize("name,w,h,passes,depth,ls", [("Demo", 96, 54, 8, 8, 2), ("Testing", 96, 54, 8, 10, 2), ("CornellBox", 64, 64, 8, 32, 2),
+                                                      ("Zoo", 64, 36, 8, 6, 1), ("MiniMesh", 64, 36, 4, 8, 2), ("MiniManyLights", 64, 36, 4, 10, 1),
+                                                      ("Empty", 16, 9, 2, 3, 1), ("RgbSpheres", 64, 36, 4, 10, 2)])
+def test_image_parity(pairs, name, w, h, passes, depth, ls):
+    sc, flat, dev, orc = pairs(name)
+    opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234)
+    job = rt.RenderJob(sc, opt, device_scene=dev)
+    job.Wait()
+    got, n = job.ReadAccum()
+    assert n == passes
+    ref, rst = orc.render(opt, threads=8)
+    # Same RNG keys and the same one-rounding-per-operator arithmetic: almost every path is identical and differs only
+    # by libm (sin/cos/pow/log/acos) ulps and the forward-throughput vs reverse-pass association of the colour sums.
+    fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert fin.mean() > 0.999
+    err = np.abs(got - ref)[fin]
+    scale = np.maximum(np.abs(ref)[fin], 1e-3)
+    close = (err <= 1e-3 * scale + 1e-5).all(axis=1).mean()
+    assert close > 0.97, f"only {close:.4f} of pixels match the oracle's sums"
+    for c in range(3):
+        m_ref, m_got = ref[fin][:, c].mean(), got[fin][:, c].mean()
+        assert abs(m_got - m_ref) <= 0.005 * max(abs(m_ref), 1e-6) + 1e-6, f"channel {c}: {m_got} vs {m_ref}"
+    # tonemapped bytes
+    img = job.Image
+    ref_img = ob.resolve_rgb24(ref, passes)
+    assert (np.abs(img.astype(int) - ref_img.astype(int)) <= 2).mean() > 0.97
+    # stats: identical definitions on both sides
+    st = job.RenderStats
+    assert st.PixelsRendered == w * h * passes == rst["pixels_rendered"]
+    assert st.PassesRendered == passes
+    assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] + 2
+    assert abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"] + 2
+    assert st.SkyRays + st.BounceLimitExceeded == st.PixelsRendered
+    assert abs(sum(st.RayDepthCounts) - sum(rst["ray_depth_counts"])) <= 0.002 * st.PixelsRendered + 2      # RenderJob.cs:458
+    job.Dispose()
+
+
+def test_sky_region_rgb24_exact_vs_golden(pairs, golden_dir):
+    """The Demo scene's sky at full 1920x1080: many passes average the jitter, and the bytes match the reference's
+    committed render (tests/golden/demo_sky_pixels.npz) within 2 LSB, almost all exactly."""
+    import os
+    sc, flat, dev, orc = pairs("Demo")
+    g = np.load(os.path.join(golden_dir, "demo_sky_pixels.npz"))
+    opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=16, MaxBounceDepth=8, Seed=3)
+    job = rt.RenderJob(sc, opt, device_scene=dev)
+    job.Wait()
+    got = job.Image[g["y_top"], g["x"]]
+    diff = np.abs(got.astype(int) - g["rgb"].astype(int))
+    assert diff.max() <= 2
+    assert (diff.max(axis=1) == 0).mean() > 0.9
+    job.Dispose()
+
+
+def test_pass_sharding_is_partition_independent(pairs):
+    """Passes {0,2,4,6} and {1,3,5,7} rendered separately sum to the single-job result up to float association."""
+    sc, flat, dev, orc = pairs("Testing")
+    opt = RenderOptions(RenderWidth=80, RenderHeight=45, Passes=8, Seed=77)
+    full = rt.RenderJob(sc, opt, device_scene=dev); full.Wait(); a, _ = full.ReadAccum()
+    parts = []
+    for r in range(2):
+        j = rt.RenderJob(sc, opt, device_scene=dev)
+        j.RenderPasses(*rt.shard_passes(8, r, 2))
+        parts.append(j.ReadAccum()[0]); j.Dispose()
+    assert np.allclose(parts[0] + parts[1], a, rtol=1e-5, atol=1e-6)
+    # batching does not change a single bit: passes_per_batch only regroups identical work
+    opt1 = RenderOptions(RenderWidth=80, RenderHeight=45, Passes=8, Seed=77, PassesPerBatch=3)
+    j = rt.RenderJob(sc, opt1, device_scene=dev); j.Wait(); b, _ = j.ReadAccum(); j.Dispose()
+    assert np.array_equal(a, b)
+    full.Dispose()
+
+
+def test_rejections_through_the_c_abi(pairs):
+    import ctypes as C
+    from raytracer_amd import capi
+    sc, flat, dev, orc = pairs("Sphere")
+    lib = capi.load()
+    bad = rt.render_job.make_opts(RenderOptions(RenderWidth=8, RenderHeight=8))
+    bad.debug_visualisation = 5
+    h = C.c_void_p()
+    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -2        # RT_ERR_UNSUPPORTED
+    bad.debug_visualisation = 0; bad.light_sample_count_hint = 0
+    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -1
+    # an unknown hittable type is rejected, not emulated
+    flat2 = flatten_scene(bs.SphereScene())
+    objs = np.ctypeslib.as_array(C.cast(flat2.desc.objects, C.POINTER(C.c_uint32)), shape=(9,))
+    objs[0] = 77
+    assert lib.rt_scene_create(C.byref(flat2.desc), -1, C.byref(h)) == -2
