@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the per-sample trace loop on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1], "Night Spheres" 1920x1080 — BuiltinScenes.Testing with a
+seeded generator: 479 spheres + ground plane + 1 DiffuseSphereLight, depth 10, 2 light samples.
+One step = PASSES_PER_STEP (8) passes over the whole 1080p frame = 16.6 M samples traced, shaded and accumulated;
+the default 32 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
+timed region.  With N > 1 every rank renders its own passes (rank, rank+N, ...) — weak scaling — and the timed
+region ends with the one sum-reduce of the colour buffers to rank 0 (RCCL) and the RGB24 resolve.
+
+Adds to the JSON line: "roofline" (dominant kernel, algorithmic flops / event-timed duration, SURVEY §8d cost
+model) and "cpu_baseline" (oracle/ — the C++ restatement of RenderInternal — on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PASSES_PER_STEP = 8
+WIDTH, HEIGHT = 1920, 1080
+MAX_DEPTH, LIGHT_SAMPLES = 10, 2
+VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+# SURVEY §8d cost model: flops / bytes per box test and per primitive test
+F_NODE, B_NODE = 22, 32
+F_PRIM = {"sphere": 28, "plane": 12}
+B_PRIM = {"sphere": 16, "plane": 24}
+
+
+def algorithmic_work(stats_delta, which):
+    """Flops and bytes of the closest-hit or the any-hit kernel from the counters (identical definitions in oracle and kernels).
+    Night Spheres holds one unbounded InfinitePlane (tested once per ray, outside the BVH) and spheres (every BVH leaf)."""
+    if which == "closest":
+        rays, V, T = stats_delta["ray_count"], stats_delta["node_visits"], stats_delta["prim_tests"]
+        extra = 0
+    else:
+        rays, V, T = stats_delta["shadow_rays"], stats_delta["shadow_node_visits"], stats_delta["shadow_prim_tests"]
+        extra = 60 * rays                                  # light sampling + attenuation per generated shadow ray
+    t_plane = min(rays, T)
+    t_sphere = T - t_plane
+    flops = F_NODE * V + F_PRIM["sphere"] * t_sphere + F_PRIM["plane"] * t_plane + extra
+    byts = B_NODE * V + B_PRIM["sphere"] * t_sphere + B_PRIM["plane"] * t_plane
+    return flops, byts
+
+
+def stats_dict(job):
+    s = job.UpdateStats()
+    return {"ray_count": s.RayCount, "shadow_rays": s.ShadowRays, "node_visits": s.NodeVisits, "prim_tests": s.PrimTests,
+            "shadow_node_visits": s.ShadowNodeVisits, "shadow_prim_tests": s.ShadowPrimTests, "pixels": s.PixelsRendered}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only trace path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as rt
+    from raytracer_amd.core import RenderOptions
+
+    scene = rt.BuiltinScenes.Testing()
+    t0 = time.perf_counter()
+    dev_scene = rt.DeviceScene(scene, local_rank)
+    scene_upload_s = time.perf_counter() - t0
+    total_steps = args.warmup + args.steps
+    opt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=total_steps * PASSES_PER_STEP * world, MaxBounceDepth=MAX_DEPTH,
+                        LightSampleCountHint=LIGHT_SAMPLES, PassesPerBatch=PASSES_PER_STEP)
+    job = rt.RenderJob(scene, opt, device=local_rank, rank=rank, world_size=world, device_scene=dev_scene)
+
+    def step(i):     # pass p of this rank's step i: global pass index rank + world * (i * PPS + j)
+        job.RenderPasses(rank + world * i * PASSES_PER_STEP, PASSES_PER_STEP, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    s0 = stats_dict(job)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i)
+    if world > 1:
+        job.ReduceToRoot()
+    if rank == 0:
+        job.UpdateImage(total_samples=total_steps * PASSES_PER_STEP * world if world > 1 else None)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    s1 = stats_dict(job)
+    d = {k: s1[k] - s0[k] for k in s0}
+    if world > 1:
+        t = torch.tensor([d["ray_count"], d["shadow_rays"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        rays_all, shadow_all = float(t[0].item()), float(t[1].item())
+    else:
+        rays_all, shadow_all = float(d["ray_count"]), float(d["shadow_rays"])
+
+    samples = WIDTH * HEIGHT * PASSES_PER_STEP * args.steps * world
+    out = {
+        "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Night Spheres (BuiltinScenes.Testing, seed 0x5EED) 1920x1080, depth 10, 2 light samples, "
+                               f"{PASSES_PER_STEP} passes per step ({args.steps * PASSES_PER_STEP * world} spp timed)",
+                   "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"pass-sharded x{world}"},
+        "mrays_per_s": {"closest": rays_all / dt / 1e6, "shadow": shadow_all / dt / 1e6, "total": (rays_all + shadow_all) / dt / 1e6},
+        "scene_upload_and_bvh_s": scene_upload_s,
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # a separate, event-timed leg (same workload, 2 more steps): per-kernel durations on the library's own stream
+        job.SetProfiling(True)
+        p0 = stats_dict(job)
+        for i in range(2):
+            step(total_steps + i)
+        prof = job.KernelProfile()
+        job.SetProfiling(False)
+        p1 = stats_dict(job)
+        pd = {k: p1[k] - p0[k] for k in p0}
+        dominant = max(("closest", "shadow"), key=lambda k: prof[k]["total_ms"])
+        flops, byts = algorithmic_work(pd, dominant)
+        sec = prof[dominant]["total_ms"] / 1e3
+        launches = prof[dominant]["launches"]
+        achieved = flops / sec / 1e12
+        out["roofline"] = {"kernel": "k_" + dominant, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                           "launches": launches, "avg_launch_ms": prof[dominant]["total_ms"] / max(launches, 1),
+                           "algorithmic_flops_per_launch": flops / max(launches, 1), "algorithmic_bytes_per_launch": byts / max(launches, 1),
+                           "hbm": {"achieved": byts / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / sec / 1e9 / HBM_PEAK_GBS},
+                           "note": "scene (31 KB of nodes + 8 KB of spheres) is cache-resident: the bound is FP32 VALU issue + latency, not HBM or MFMA; "
+                                   "peak counts an FMA as 2 flops, the kernels run with -ffp-contract=off (bit-parity), i.e. at most half of it"}
+        out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        threads = min(16, os.cpu_count() or 1)
+        cw, ch, cp = 960, 540, 2
+        copt = RenderOptions(RenderWidth=cw, RenderHeight=ch, Passes=cp, MaxBounceDepth=MAX_DEPTH, LightSampleCountHint=LIGHT_SAMPLES)
+        osc = ob.OracleScene(dev_scene.flat)
+        t0 = time.perf_counter()
+        osc.render(copt, threads=threads)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cw * ch * cp / cdt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                               "sample": f"same scene and options at {cw}x{ch}, {cp} passes ({cw * ch * cp} samples, {cdt:.1f} s)"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    job.Dispose()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

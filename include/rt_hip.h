@@ -338,6 +338,19 @@ int rt_render_read_accum(rt_render* render, float* rgb_sum /* width*height*3 */,
 int rt_render_resolve_device(rt_render* render, const float* accum_device, uint32_t sample_count, uint8_t* dst_host);
 int rt_render_stats(rt_render* render, rt_stats* out);
 
+/* Per-kernel timing of the trace loop, measured with HIP events on the stream the kernels are launched on.
+ * No reference counterpart (the reference only keeps a Stopwatch, RenderJob.cs:72,124); bench.py's roofline
+ * figures come from here.  Off by default; while on, every launch is bracketed by two event records. */
+typedef enum rt_kernel_class {
+    RT_K_RAYGEN = 0, RT_K_CLOSEST = 1, RT_K_SHADE = 2, RT_K_SHADOW = 3, RT_K_ACCUMULATE = 4, RT_K_RESOLVE = 5, RT_K_COUNT = 6
+} rt_kernel_class;
+typedef struct rt_kernel_profile {
+    uint64_t launches[RT_K_COUNT];
+    double   total_ms[RT_K_COUNT];
+} rt_kernel_profile;
+int rt_render_set_profiling(rt_render* render, int enable);          /* also clears the totals */
+int rt_render_kernel_profile(rt_render* render, rt_kernel_profile* out);
+
 /* Parity hooks: RenderJob.TryFindClosestHit (RenderJob.cs:581-617) and AnyIntersectionFast (:575)
  * on caller-supplied rays. Ray i uses RNG key (seed, pixel=i, pass=0, depth=0) where an
  * intersector draws random numbers (ConstantDensityMedium.cs:56,63). */

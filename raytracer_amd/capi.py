@@ -123,6 +123,16 @@ class Stats(C.Structure):
         return d
 
 
+RT_K_NAMES = ("raygen", "closest", "shade", "shadow", "accumulate", "resolve")
+
+
+class KernelProfile(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * 6), ("total_ms", C.c_double * 6)]
+
+    def as_dict(self):
+        return {n: {"launches": int(self.launches[i]), "total_ms": float(self.total_ms[i])} for i, n in enumerate(RT_K_NAMES)}
+
+
 class Ray(C.Structure):
     _fields_ = [("origin", F3), ("direction", F3)]
 
@@ -146,6 +156,8 @@ SYMBOLS = {
     "rt_render_read_accum": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rt_render_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rt_render_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "rt_render_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_render_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile)]),
     "rt_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "rt_trace_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

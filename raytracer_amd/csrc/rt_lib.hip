@@ -83,7 +83,42 @@ struct rt_render {
     uint64_t passes_rendered = 0;
     DevBuf f32_pool, u32_pool, counters, stats, accum_buf, rgb;
     std::vector<unsigned long long> stats_host;
+    // per-kernel event timing (rt_render_set_profiling)
+    bool profiling = false;
+    struct Stamp { int cls; hipEvent_t a, b; };
+    std::vector<Stamp> stamps;              // recorded, not yet read
+    std::vector<hipEvent_t> free_events;
+    rt_kernel_profile prof{};
 };
+
+namespace {
+// Brackets one launch with two event records when profiling is on.
+struct Timed {
+    rt_render* r; int cls; hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(rt_render* r) {
+        if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+    }
+    Timed(rt_render* r_, int cls_) : r(r_), cls(cls_) {
+        if (!r->profiling) return;
+        a = get(r); b = get(r);
+        if (a) (void)hipEventRecord(a, r->stream);
+    }
+    ~Timed() {
+        if (!r->profiling) return;
+        if (b) (void)hipEventRecord(b, r->stream);
+        if (a && b) r->stamps.push_back({cls, a, b});
+    }
+};
+void collect_stamps(rt_render* r) {       // call after the stream has been synchronised
+    for (auto& s : r->stamps) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { r->prof.launches[s.cls]++; r->prof.total_ms[s.cls] += ms; }
+        r->free_events.push_back(s.a); r->free_events.push_back(s.b);
+    }
+    r->stamps.clear();
+}
+} // namespace
 
 extern "C" {
 
@@ -385,6 +420,8 @@ int rt_render_destroy(rt_render* r) {
     if (!r) return RT_OK;
     DeviceGuard guard(r->scene->device);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
+    collect_stamps(r);
+    for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
     return RT_OK;
@@ -400,13 +437,13 @@ static int enqueue_batch(rt_render* r, uint64_t first, uint32_t np, uint32_t str
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
     const size_t lds = stack_bytes(s);
-    hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd);
+    { Timed t(r, RT_K_RAYGEN); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= r->opts.max_bounce_depth; depth++) {
-        hipLaunchKernelGGL(k_closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
-        hipLaunchKernelGGL(k_shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth);
-        if (s->n_lights) hipLaunchKernelGGL(k_shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
+        { Timed t(r, RT_K_CLOSEST); hipLaunchKernelGGL(k_closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+        { Timed t(r, RT_K_SHADE); hipLaunchKernelGGL(k_shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
+        if (s->n_lights) { Timed t(r, RT_K_SHADOW); hipLaunchKernelGGL(k_shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, rd.n_pixels, 8)), dim3(BLOCK), 0, st, rd, r->accum, np);
+    { Timed t(r, RT_K_ACCUMULATE); hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, rd.n_pixels, 8)), dim3(BLOCK), 0, st, rd, r->accum, np); }
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -423,6 +460,7 @@ int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint3
         done += np;
     }
     HIP_TRY(hipStreamSynchronize(r->stream));
+    collect_stamps(r);
     r->sample_count += n_passes; r->passes_rendered += n_passes;
     return RT_OK;
 }
@@ -432,10 +470,11 @@ int rt_render_resolve_device(rt_render* r, const float* accum_device, uint32_t s
     if (sample_count < 1) return fail(RT_ERR_INVALID_ARG, "rt_render_resolve_device: no samples to resolve");
     DeviceGuard guard(r->scene->device);
     const size_t nv = (size_t)r->rd.n_pixels * 3;
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(r->scene, nv, 8)), dim3(BLOCK), 0, r->stream, accum_device, sample_count, nv, r->rgb.as<uint8_t>());
+    { Timed t(r, RT_K_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(grid_for(r->scene, nv, 8)), dim3(BLOCK), 0, r->stream, accum_device, sample_count, nv, r->rgb.as<uint8_t>()); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(dst_host, r->rgb.p, nv, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
+    collect_stamps(r);
     return RT_OK;
 }
 
@@ -465,6 +504,25 @@ int rt_render_stats(rt_render* r, rt_stats* out) {
     out->sky_rays = h[ST_SKY]; out->bounce_limit_exceeded = h[ST_LIMIT]; out->ray_count = h[ST_RAYS]; out->shadow_rays = h[ST_SHADOW_RAYS];
     out->node_visits = h[ST_NODES]; out->prim_tests = h[ST_PRIMS]; out->shadow_node_visits = h[ST_SH_NODES]; out->shadow_prim_tests = h[ST_SH_PRIMS];
     for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) out->ray_depth_counts[i] = h[ST_DEPTH0 + i];
+    return RT_OK;
+}
+
+int rt_render_set_profiling(rt_render* r, int enable) {
+    if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_set_profiling: null handle");
+    DeviceGuard guard(r->scene->device);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    collect_stamps(r);
+    r->profiling = enable != 0;
+    memset(&r->prof, 0, sizeof(r->prof));
+    return RT_OK;
+}
+
+int rt_render_kernel_profile(rt_render* r, rt_kernel_profile* out) {
+    if (!r || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_kernel_profile: null argument");
+    DeviceGuard guard(r->scene->device);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    collect_stamps(r);
+    *out = r->prof;
     return RT_OK;
 }
 

@@ -216,6 +216,14 @@ class RenderJob:
         s.RayDepthCounts = [int(x) for x in st.ray_depth_counts]
         return s
 
+    def SetProfiling(self, enable: bool):
+        capi.check(self._lib.rt_render_set_profiling(self.handle, 1 if enable else 0))
+
+    def KernelProfile(self) -> dict:
+        kp = capi.KernelProfile()
+        capi.check(self._lib.rt_render_kernel_profile(self.handle, C.byref(kp)))
+        return kp.as_dict()
+
     # ---- RenderJob.cs:733 -------------------------------------------------------------------------------------------
     def Dispose(self):
         if self.handle:
