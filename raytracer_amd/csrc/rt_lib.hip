@@ -360,7 +360,7 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
     if (o->device >= 0 && o->device != s->device) return fail(RT_ERR_INVALID_ARG, "render device %d differs from the scene's device %d", o->device, s->device);
     const uint64_t n_pixels = (uint64_t)o->width * o->height;
-    if (n_pixels > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "more than 2^31 pixels");
+    if (n_pixels > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
 
     DeviceGuard guard(s->device);
     auto r = std::make_unique<rt_render>();
@@ -368,7 +368,7 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     // paths per batch: enough to keep 256 CUs busy at deep bounces, bounded so the state stays a few GiB
     const uint64_t target_paths = 16ull << 20;
     uint32_t ppb = o->passes_per_batch ? o->passes_per_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
-    if (n_pixels * ppb > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^31 paths");
+    if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
     r->passes_per_batch = ppb;
     const size_t P = (size_t)(n_pixels * ppb);
     r->max_paths = P;
