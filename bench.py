@@ -5,8 +5,8 @@
 
 Workload (config.workload): BASELINE.json configs[1], "Night Spheres" 1920x1080 — BuiltinScenes.Testing with a
 seeded generator: 479 spheres + ground plane + 1 DiffuseSphereLight, depth 10, 2 light samples.
-One step = PASSES_PER_STEP (8) passes over the whole 1080p frame = 16.6 M samples traced, shaded and accumulated;
-the default 32 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
+One step = PASSES_PER_STEP (32) passes over the whole 1080p frame = 66.4 M samples traced, shaded and accumulated
+(four wavefront batches of 8 passes); the default 8 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
 timed region.  With N > 1 every rank renders its own passes (rank, rank+N, ...) — weak scaling — and the timed
 region ends with the one sum-reduce of the colour buffers to rank 0 (RCCL) and the RGB24 resolve.
 
@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PASSES_PER_STEP = 8
+PASSES_PER_STEP = 32      # passes per step (one blocking rt_render_passes call)
+PASSES_PER_BATCH = 8      # passes per wavefront batch (16.6 M paths); the library keeps several batches in flight
 WIDTH, HEIGHT = 1920, 1080
 MAX_DEPTH, LIGHT_SAMPLES = 10, 2
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
@@ -60,8 +61,8 @@ def stats_dict(job):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -92,7 +93,7 @@ def main():
     scene_upload_s = time.perf_counter() - t0
     total_steps = args.warmup + args.steps
     opt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=total_steps * PASSES_PER_STEP * world, MaxBounceDepth=MAX_DEPTH,
-                        LightSampleCountHint=LIGHT_SAMPLES, PassesPerBatch=PASSES_PER_STEP)
+                        LightSampleCountHint=LIGHT_SAMPLES, PassesPerBatch=PASSES_PER_BATCH)
     job = rt.RenderJob(scene, opt, device=local_rank, rank=rank, world_size=world, device_scene=dev_scene)
 
     def step(i):     # pass p of this rank's step i: global pass index rank + world * (i * PPS + j)
@@ -138,13 +139,14 @@ def main():
                    "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"pass-sharded x{world}"},
         "mrays_per_s": {"closest": rays_all / dt / 1e6, "shadow": shadow_all / dt / 1e6, "total": (rays_all + shadow_all) / dt / 1e6},
         "scene_upload_and_bvh_s": scene_upload_s,
+        "ray_depth_counts": job.RenderStats.RayDepthCounts[:MAX_DEPTH + 1],
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        # a separate, event-timed leg (same workload, 2 more steps): per-kernel durations on the library's own stream
+        # a separate, event-timed leg (same workload, 1 more step, batches one at a time): per-kernel durations on the library's own stream
         job.SetProfiling(True)
         p0 = stats_dict(job)
-        for i in range(2):
+        for i in range(1):
             step(total_steps + i)
         prof = job.KernelProfile()
         job.SetProfiling(False)

@@ -45,14 +45,13 @@ BuildResult build(const std::vector<Box>& boxes, const std::vector<uint32_t>& ob
     res.nodes.reserve(n > 1 ? n - 1 : 1);
     auto set_child = [&](int32_t parent, int side, int32_t code, const Box& b) {
         HostNode& p = res.nodes[parent];
-        float* q = p.q + (side ? 6 : 0);
-        q[0] = b.mn[0]; q[1] = b.mn[1]; q[2] = b.mn[2]; q[3] = b.mx[0]; q[4] = b.mx[1]; q[5] = b.mx[2];
+        for (int a = 0; a < 3; a++) { p.q[2 * a + side] = b.mn[a]; p.q[6 + 2 * a + side] = b.mx[a]; }
         (side ? p.childB : p.childA) = code;
     };
     auto new_node = [&]() -> int32_t {
         HostNode nd; std::memset(&nd, 0, sizeof(nd));
         Box e = empty_box();
-        for (int s = 0; s < 2; s++) { float* q = nd.q + 6 * s; q[0] = e.mn[0]; q[1] = e.mn[1]; q[2] = e.mn[2]; q[3] = e.mx[0]; q[4] = e.mx[1]; q[5] = e.mx[2]; }
+        for (int s = 0; s < 2; s++) for (int a = 0; a < 3; a++) { nd.q[2 * a + s] = e.mn[a]; nd.q[6 + 2 * a + s] = e.mx[a]; }
         nd.childA = CHILD_EMPTY; nd.childB = CHILD_EMPTY;
         res.nodes.push_back(nd);
         return (int32_t)res.nodes.size() - 1;

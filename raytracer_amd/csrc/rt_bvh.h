@@ -14,7 +14,7 @@ namespace rtbvh {
 struct Box { float mn[3], mx[3]; };
 
 struct HostNode {            // mirrors rtd::Node
-    float q[12];             // minA.xyz maxA.xyz minB.xyz maxB.xyz
+    float q[12];             // min.x(A,B) min.y(A,B) min.z(A,B) max.x(A,B) max.y(A,B) max.z(A,B)
     int32_t childA, childB;  // >= 0 inner, < 0 leaf (~object), CHILD_EMPTY none
     int32_t pad0, pad1;
 };

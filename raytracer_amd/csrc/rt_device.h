@@ -83,8 +83,9 @@ RT_FN f3 on_unit_sphere(float a, float b, float c) {                            
 // Scene tables in HBM.  Records are float4-aligned so one or two 16-B loads fetch a primitive.
 // ------------------------------------------------------------------------------------------------
 // BVH2 node, 64 B: both children's boxes + both child codes -> one 64-B line per visit.
-//   q0 = (minA.x minA.y minA.z maxA.x)  q1 = (maxA.y maxA.z minB.x minB.y)  q2 = (minB.z maxB.x maxB.y maxB.z)
-//   q3 = (childA, childB, -, -) as int bits: >= 0 inner node index, < 0 leaf holding object ~code, CHILD_EMPTY = none.
+//   q0 = (minA.x minB.x minA.y minB.y)  q1 = (minA.z minB.z maxA.x maxB.x)  q2 = (maxA.y maxB.y maxA.z maxB.z)
+//   (A/B interleaved so that one packed-f32 instruction works on both boxes)
+//   q3 = (childA, childB, -, -) as int bits: >= 0 inner node index, < 0 leaf holding object ~index, CHILD_EMPTY = none.
 // Leaves hold exactly one object and the leaf's box is that object's Hittable.BoundingVolume, so testing it
 // is the reference's SingleObjectBvhNode box test (Core/Acceleration/SingleObjectBvhNode.cs:12-16).
 struct Node { float4 q0, q1, q2; int4 q3; };
@@ -145,6 +146,35 @@ RT_FN bool slab_hit(float entry, float exit_, float kMax) {
     float hi = exit_ < kMax ? exit_ : kMax;     // a NaN exit (every axis degenerate) leaves kMax, as the reference's selects do
     return !(hi <= entry);
 }
+
+// Both boxes of one node at once.  Bit-identical to two slab() calls: the same subtract and multiply per plane (packed-f32,
+// v_pk_add_f32 / v_pk_mul_f32 on the A/B pair), the swap is a select on the sign of invD, and the reference's `?:` folds are
+// exactly maxNum / minNum chains (a NaN plane distance never replaces a bound), i.e. v_max3_f32 / v_min3_f32.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RaySigns { bool x, y, z; };
+RT_FN void slab_pair(float4 q0, float4 q1, float4 q2, f3 o, f3 invD, RaySigns neg, float kMin, float& enA, float& exA, float& enB, float& exB) {
+    v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {invD.x, invD.x}, iy = {invD.y, invD.y}, iz = {invD.z, invD.z};
+    v2f mnx = {q0.x, q0.y}, mny = {q0.z, q0.w}, mnz = {q1.x, q1.y}, mxx = {q1.z, q1.w}, mxy = {q2.x, q2.y}, mxz = {q2.z, q2.w};
+    v2f ax = (mnx - ox) * ix, bx = (mxx - ox) * ix;
+    v2f ay = (mny - oy) * iy, by = (mxy - oy) * iy;
+    v2f az = (mnz - oz) * iz, bz = (mxz - oz) * iz;
+    v2f nx = neg.x ? bx : ax, fx = neg.x ? ax : bx;
+    v2f ny = neg.y ? by : ay, fy = neg.y ? ay : by;
+    v2f nz = neg.z ? bz : az, fz = neg.z ? az : bz;
+    enA = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.x, kMin), ny.x), nz.x);
+    enB = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.y, kMin), ny.y), nz.y);
+    exA = __builtin_fminf(__builtin_fminf(fx.x, fy.x), fz.x);
+    exB = __builtin_fminf(__builtin_fminf(fx.y, fy.y), fz.y);
+}
+
+// Compile-time description of what a scene contains: the kernels are instantiated for a few common mixes so that the
+// intersectors, materials, textures and lights a scene does not use cost no registers and no instruction cache.
+template <uint32_t PRIMS, uint32_t MATS, uint32_t TEXS, uint32_t LIGHTS>
+struct Cfg { static constexpr uint32_t prims = PRIMS, mats = MATS, texs = TEXS, lights = LIGHTS; };
+#define RT_HAS_PRIM(C, t)  ((C::prims >> (t)) & 1u)
+#define RT_HAS_MAT(C, t)   ((C::mats >> (t)) & 1u)
+#define RT_HAS_TEX(C, t)   ((C::texs >> (t)) & 1u)
+#define RT_HAS_LIGHT(C, t) ((C::lights >> (t)) & 1u)
 
 // ------------------------------------------------------------------------------------------------
 // Intersectors.  try_* = Hittable.TryHit's decision and K; fast_* = Hittable.FastTryHit.
@@ -342,49 +372,54 @@ RT_FN bool try_cylinder(const float4* c, Ray r, float kMin, float kMax, float& k
     return true;
 }
 
-// One object, TryHit semantics.  aux carries ShaderData for media (HitRecord.ShaderData).
+// One object, TryHit semantics.
+template <class C>
 RT_FN bool try_object_solid(const SceneDev& sc, uint32_t type, uint32_t idx, Ray r, float kMin, float kMax, float& k) {
     float u, v, nd; f3 n; BoxSolve bs;
     switch (type) {
-        case RT_HIT_SPHERE:         return try_sphere(sc.spheres[idx], r, kMin, kMax, k);
-        case RT_HIT_TRIANGLE:       return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
-        case RT_HIT_QUAD:           return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
-        case RT_HIT_INFINITE_PLANE: return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd);
-        case RT_HIT_XY_PLANE:       return try_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax, k);
-        case RT_HIT_XZ_PLANE:       return try_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax, k);
-        case RT_HIT_YZ_PLANE:       return try_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax, k);
-        case RT_HIT_DISK:           return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, false);
-        case RT_HIT_BOX:            return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, false, k, bs);
-        case RT_HIT_CAPSULE:        return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, false);
-        case RT_HIT_CYLINDER:       return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, false);
-        default: return false;
+        case RT_HIT_SPHERE:         if constexpr (RT_HAS_PRIM(C, RT_HIT_SPHERE)) return try_sphere(sc.spheres[idx], r, kMin, kMax, k); break;
+        case RT_HIT_TRIANGLE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_TRIANGLE)) return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd); break;
+        case RT_HIT_QUAD:           if constexpr (RT_HAS_PRIM(C, RT_HIT_QUAD)) return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd); break;
+        case RT_HIT_INFINITE_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_INFINITE_PLANE)) return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd); break;
+        case RT_HIT_XY_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_XY_PLANE)) return try_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax, k); break;
+        case RT_HIT_XZ_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_XZ_PLANE)) return try_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax, k); break;
+        case RT_HIT_YZ_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_YZ_PLANE)) return try_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax, k); break;
+        case RT_HIT_DISK:           if constexpr (RT_HAS_PRIM(C, RT_HIT_DISK)) return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, false); break;
+        case RT_HIT_BOX:            if constexpr (RT_HAS_PRIM(C, RT_HIT_BOX)) return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, false, k, bs); break;
+        case RT_HIT_CAPSULE:        if constexpr (RT_HAS_PRIM(C, RT_HIT_CAPSULE)) return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, false); break;
+        case RT_HIT_CYLINDER:       if constexpr (RT_HAS_PRIM(C, RT_HIT_CYLINDER)) return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, false); break;
+        default: break;
     }
+    return false;
 }
 // FastTryHit semantics
+template <class C>
 RT_FN bool fast_object_solid(const SceneDev& sc, uint32_t type, uint32_t idx, Ray r, float kMin, float kMax) {
     float k, u, v, nd; f3 n; BoxSolve bs;
     switch (type) {
-        case RT_HIT_SPHERE:         return try_sphere(sc.spheres[idx], r, kMin, kMax, k);
-        case RT_HIT_TRIANGLE:       return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
-        case RT_HIT_QUAD:           return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd);
-        case RT_HIT_INFINITE_PLANE: return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd);
-        case RT_HIT_XY_PLANE:       return fast_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax);
-        case RT_HIT_XZ_PLANE:       return fast_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax);
-        case RT_HIT_YZ_PLANE:       return fast_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax);
-        case RT_HIT_DISK:           return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, true);
-        case RT_HIT_BOX:            return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, true, k, bs);
-        case RT_HIT_CAPSULE:        return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, true);
-        case RT_HIT_CYLINDER:       return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, true);
-        default: return false;
+        case RT_HIT_SPHERE:         if constexpr (RT_HAS_PRIM(C, RT_HIT_SPHERE)) return try_sphere(sc.spheres[idx], r, kMin, kMax, k); break;
+        case RT_HIT_TRIANGLE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_TRIANGLE)) return try_quad<true>(sc.triangles + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd); break;
+        case RT_HIT_QUAD:           if constexpr (RT_HAS_PRIM(C, RT_HIT_QUAD)) return try_quad<false>(sc.quads + 4 * (size_t)idx, r, kMin, kMax, k, u, v, nd); break;
+        case RT_HIT_INFINITE_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_INFINITE_PLANE)) return try_inf_plane(sc.inf_planes + 2 * (size_t)idx, r, kMin, kMax, k, nd); break;
+        case RT_HIT_XY_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_XY_PLANE)) return fast_axis_plane(sc.axis_planes[0] + 2 * (size_t)idx, 0, r, kMin, kMax); break;
+        case RT_HIT_XZ_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_XZ_PLANE)) return fast_axis_plane(sc.axis_planes[1] + 2 * (size_t)idx, 1, r, kMin, kMax); break;
+        case RT_HIT_YZ_PLANE:       if constexpr (RT_HAS_PRIM(C, RT_HIT_YZ_PLANE)) return fast_axis_plane(sc.axis_planes[2] + 2 * (size_t)idx, 2, r, kMin, kMax); break;
+        case RT_HIT_DISK:           if constexpr (RT_HAS_PRIM(C, RT_HIT_DISK)) return try_disk(sc.disks + 4 * (size_t)idx, r, kMin, kMax, k, nd, true); break;
+        case RT_HIT_BOX:            if constexpr (RT_HAS_PRIM(C, RT_HIT_BOX)) return box_core(sc.boxes + 6 * (size_t)idx, r, kMin, kMax, true, k, bs); break;
+        case RT_HIT_CAPSULE:        if constexpr (RT_HAS_PRIM(C, RT_HIT_CAPSULE)) return try_capsule(sc.capsules + 5 * (size_t)idx, r, kMin, kMax, k, true); break;
+        case RT_HIT_CYLINDER:       if constexpr (RT_HAS_PRIM(C, RT_HIT_CYLINDER)) return try_cylinder(sc.cylinders + 2 * (size_t)idx, r, kMin, kMax, k, n, true); break;
+        default: break;
     }
+    return false;
 }
 
 // ConstantDensityMedium.TryHit, ConstantDensityMedium.cs:46-68.  K = entry.K + dist, ShaderData = dist.
+template <class C>
 RT_FN bool try_medium(const SceneDev& sc, uint32_t midx, uint32_t self_obj, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, float& k, float& aux) {
     rt_medium m = sc.media_rec[midx];
     float kEntry, kExit;
-    if (!try_object_solid(sc, m.boundary_type, m.boundary_index, r, kMin, kMax, kEntry)) return false;
-    if (!try_object_solid(sc, m.boundary_type, m.boundary_index, r, kEntry + 0.001f, kMax, kExit)) return false;
+    if (!try_object_solid<C>(sc, m.boundary_type, m.boundary_index, r, kMin, kMax, kEntry)) return false;
+    if (!try_object_solid<C>(sc, m.boundary_type, m.boundary_index, r, kEntry + 0.001f, kMax, kExit)) return false;
     float between = kExit - kEntry;
     float4 u = rng_draw(key, depth, SLOT_MEDIUM, self_obj);
     float dist = m.neg_inv_density * logf(u.x);
@@ -409,57 +444,55 @@ RT_FN void consider(Closest& best, float k, uint32_t obj, float aux) {
 
 RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(r.o.z) || is_nan(r.d.x) || is_nan(r.d.y) || is_nan(r.d.z); }
 
+// One traversal loop, one code site per kind of work: `cur` is either an inner node (>= 0: test both child boxes, go to the
+// nearer hit child, push the other) or a leaf (< 0: run the object's intersector).  A leaf's box is tested when its parent is
+// visited, with the best K known then — the reference's SingleObjectBvhNode test (SingleObjectBvhNode.cs:12-16); a K found later
+// only shrinks the range the intersector accepts, so the result is the same.
+template <class C>
 RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, int* stack, int stride, TravCount& cnt) {
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
     if (ray_has_nan(r)) return best;
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
         uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
         float k; cnt.prims++;
-        if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
     }
     if (sc.n_nodes) {
-        f3 invD = splat(1.0f) / r.d;
-        int sp = 0, node = 0;
+        const f3 invD = splat(1.0f) / r.d;
+        RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
+        int sp = 0, cur = 0;
         for (;;) {
-            const Node* np = sc.nodes + node;
-            float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int4 q3 = np->q3;
-            cnt.nodes += 2;
-            float enA, exA, enB, exB;
-            slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), r.o, invD, kMin, enA, exA);
-            slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), r.o, invD, kMin, enB, exB);
-            int cA = q3.x, cB = q3.y;
-            bool hA = (cA != CHILD_EMPTY) && slab_hit(enA, exA, best.k);
-            bool hB = (cB != CHILD_EMPTY) && slab_hit(enB, exB, best.k);
-            // order: nearer entry first (affects only the amount of work, not the result)
-            if (hA && hB && enB < enA) { int t = cA; cA = cB; cB = t; float e = enA; enA = enB; enB = e; e = exA; exA = exB; exB = e; }
-            else if (!hA && hB) { cA = cB; enA = enB; exA = exB; hA = true; hB = false; }
-            int next = -1;
-            if (hA) {
-                if (cA < 0) {
-                    uint32_t obj = (uint32_t)~cA, code = sc.obj_code[obj]; float k; cnt.prims++;
-                    if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
-                } else next = cA;
+            if (cur >= 0) {
+                const Node* np = sc.nodes + cur;
+                float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int2 ch = *(const int2*)&np->q3;
+                cnt.nodes += 2;
+                float enA, exA, enB, exB;
+                slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+                const bool hA = (ch.x != CHILD_EMPTY) && slab_hit(enA, exA, best.k);
+                const bool hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, best.k);
+                if (hA && hB) {                                    // nearer entry first (affects only the amount of work)
+                    const bool bFirst = enB < enA;
+                    stack[sp * stride] = bFirst ? ch.x : ch.y; sp++;
+                    cur = bFirst ? ch.y : ch.x;
+                    continue;
+                }
+                if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
+            } else {
+                uint32_t obj = (uint32_t)~cur, code = sc.obj_code[obj]; float k; cnt.prims++;
+                if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
             }
-            if (hB) {
-                if (cB < 0) {
-                    if (slab_hit(enB, exB, best.k)) {      // leaf box test with the kMax current at the time, as the reference's recursion does
-                        uint32_t obj = (uint32_t)~cB, code = sc.obj_code[obj]; float k; cnt.prims++;
-                        if (try_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
-                    }
-                } else if (next < 0) next = cB;
-                else { stack[sp * stride] = cB; sp++; }
-            }
-            if (next >= 0) { node = next; continue; }
             if (sp == 0) break;
-            sp--; node = stack[sp * stride];
+            sp--; cur = stack[sp * stride];
         }
     }
-    for (uint32_t i = 0; i < sc.n_media; i++) {
-        uint32_t obj = sc.media[i], code = sc.obj_code[obj];
-        float k, aux; cnt.prims++;
-        // SingleObjectBvhNode box test (the medium's BoundingVolume is its boundary's, ConstantDensityMedium.cs:80) is implied:
-        // the boundary intersector only returns points inside that box.
-        if (try_medium(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+    if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
+        for (uint32_t i = 0; i < sc.n_media; i++) {
+            uint32_t obj = sc.media[i], code = sc.obj_code[obj];
+            float k, aux; cnt.prims++;
+            // SingleObjectBvhNode box test (the medium's BoundingVolume is its boundary's, ConstantDensityMedium.cs:80) is implied:
+            // the boundary intersector only returns points inside that box.
+            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+        }
     }
     // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
     if (best.obj != RT_NO_HIT && !((best.k >= kMin) && (best.k <= kMax))) best.obj = RT_NO_HIT;
@@ -468,47 +501,41 @@ RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, con
 
 // RenderJob.AnyIntersectionFast, Core/RenderJob.cs:575.  The reference scans every object's FastTryHit; culling by
 // conservative boxes returns the same boolean.
+template <class C>
 RT_FN bool any_hit(const SceneDev& sc, Ray r, float kMin, float kMax, int* stack, int stride, TravCount& cnt) {
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
         uint32_t code = sc.obj_code[sc.unbounded[i]]; cnt.prims++;
-        if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
+        if (fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
     }
-    for (uint32_t i = 0; i < sc.n_media; i++) {
-        rt_medium m = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; cnt.prims++;
-        if (fast_object_solid(sc, m.boundary_type, m.boundary_index, r, kMin, kMax)) return true;      // ConstantDensityMedium.cs:77
+    if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
+        for (uint32_t i = 0; i < sc.n_media; i++) {
+            rt_medium m = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; cnt.prims++;
+            if (fast_object_solid<C>(sc, m.boundary_type, m.boundary_index, r, kMin, kMax)) return true;      // ConstantDensityMedium.cs:77
+        }
     }
     if (!sc.n_nodes) return false;
-    f3 invD = splat(1.0f) / r.d;
-    int sp = 0, node = 0;
+    const f3 invD = splat(1.0f) / r.d;
+    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
+    int sp = 0, cur = 0;
     for (;;) {
-        const Node* np = sc.nodes + node;
-        float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int4 q3 = np->q3;
-        cnt.nodes += 2;
-        float enA, exA, enB, exB;
-        slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), r.o, invD, kMin, enA, exA);
-        slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), r.o, invD, kMin, enB, exB);
-        int cA = q3.x, cB = q3.y;
-        // any-hit boxes use a closed interval (exit >= entry) so a hit exactly on a box face is never culled
-        float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
-        bool hA = (cA != CHILD_EMPTY) && !(hiA < enA);
-        bool hB = (cB != CHILD_EMPTY) && !(hiB < enB);
-        int next = -1;
-        if (hA) {
-            if (cA < 0) {
-                uint32_t code = sc.obj_code[(uint32_t)~cA]; cnt.prims++;
-                if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
-            } else next = cA;
+        if (cur >= 0) {
+            const Node* np = sc.nodes + cur;
+            float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int2 ch = *(const int2*)&np->q3;
+            cnt.nodes += 2;
+            float enA, exA, enB, exB;
+            slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+            // any-hit boxes use a closed interval (exit >= entry) so a hit exactly on a box face is never culled
+            const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
+            const bool hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
+            const bool hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
+            if (hA && hB) { stack[sp * stride] = ch.y; sp++; cur = ch.x; continue; }
+            if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
+        } else {
+            uint32_t code = sc.obj_code[(uint32_t)~cur]; cnt.prims++;
+            if (fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
         }
-        if (hB) {
-            if (cB < 0) {
-                uint32_t code = sc.obj_code[(uint32_t)~cB]; cnt.prims++;
-                if (fast_object_solid(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
-            } else if (next < 0) next = cB;
-            else { stack[sp * stride] = cB; sp++; }
-        }
-        if (next >= 0) { node = next; continue; }
         if (sp == 0) break;
-        sp--; node = stack[sp * stride];
+        sp--; cur = stack[sp * stride];
     }
     return false;
 }
@@ -525,21 +552,21 @@ RT_FN void sphere_uv(f3 p, float& u, float& v) {                                
     v = theta / PI_F;
 }
 
-template <bool WANT_UV>
+template <class C, bool WANT_UV>
 RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& key, uint32_t depth) {
     HitRec h; h.k = c.k; h.obj = c.obj; h.mat = sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
     uint32_t code = sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
     h.wp = point_at(r.o, r.d, c.k);
     h.n = mk3(0, 0, 0);
     switch (type) {
-        case RT_HIT_SPHERE: {                                                            // Sphere.cs:59-70
+        case RT_HIT_SPHERE: if constexpr (RT_HAS_PRIM(C, RT_HIT_SPHERE)) {                                                            // Sphere.cs:59-70
             float4 s = sc.spheres[idx];
             f3 outN = normalize(h.wp - mk3(s.x, s.y, s.z));
             bool inside = dot(r.d, outN) > 0.0f;
             h.n = inside ? -outN : outN; h.outside = !inside;
             if (WANT_UV) sphere_uv(outN, h.u, h.v);
         } break;
-        case RT_HIT_QUAD: case RT_HIT_TRIANGLE: {                                        // Quad.cs:100-119
+        case RT_HIT_QUAD: case RT_HIT_TRIANGLE: if constexpr (RT_HAS_PRIM(C, RT_HIT_QUAD) || RT_HAS_PRIM(C, RT_HIT_TRIANGLE)) {                                        // Quad.cs:100-119
             const float4* q = (type == RT_HIT_QUAD ? sc.quads : sc.triangles) + 4 * idx;
             float4 q0 = q[0], q1 = q[1];
             h.n = mk3(q1.x, q1.y, q1.z);
@@ -550,24 +577,24 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                 h.v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
             }
         } break;
-        case RT_HIT_INFINITE_PLANE: {                                                    // InfinitePlane.cs:55-60
+        case RT_HIT_INFINITE_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_INFINITE_PLANE)) {                                                    // InfinitePlane.cs:55-60
             float4 p1 = sc.inf_planes[2 * idx + 1];
             h.n = mk3(p1.x, p1.y, p1.z);
             h.outside = dot(r.d, h.n) < 0;
         } break;
-        case RT_HIT_XY_PLANE: case RT_HIT_XZ_PLANE: case RT_HIT_YZ_PLANE: {              // XYPlane.cs:69-101
+        case RT_HIT_XY_PLANE: case RT_HIT_XZ_PLANE: case RT_HIT_YZ_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_XY_PLANE) || RT_HAS_PRIM(C, RT_HIT_XZ_PLANE) || RT_HAS_PRIM(C, RT_HIT_YZ_PLANE)) {              // XYPlane.cs:69-101
             int axis = type - RT_HIT_XY_PLANE;
             const float4* p = sc.axis_planes[axis] + 2 * idx;
-            float4 p0 = p[0]; float C = p[1].x;
+            float4 p0 = p[0]; float planeC = p[1].x;
             float oC = axis == 0 ? r.o.z : axis == 1 ? r.o.y : r.o.x;
             f3 unit = axis == 0 ? mk3(0, 0, 1) : axis == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0);
-            h.n = oC < C ? -unit : unit;
+            h.n = oC < planeC ? -unit : unit;
             if (WANT_UV) {
                 float a = axis == 2 ? h.wp.y : h.wp.x, b = axis == 0 ? h.wp.y : h.wp.z;
                 h.u = (a - p0.x) / (p0.y - p0.x); h.v = (b - p0.z) / (p0.w - p0.z);
             }
         } break;
-        case RT_HIT_DISK: {                                                              // Disk.cs:83-97
+        case RT_HIT_DISK: if constexpr (RT_HAS_PRIM(C, RT_HIT_DISK)) {                                                              // Disk.cs:83-97
             const float4* d = sc.disks + 4 * idx;
             float4 d0 = d[0], d1 = d[1];
             h.n = mk3(d1.x, d1.y, d1.z);
@@ -583,7 +610,7 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                 h.u = u; h.v = v;
             }
         } break;
-        case RT_HIT_BOX: {                                                               // Box.cs:147-182
+        case RT_HIT_BOX: if constexpr (RT_HAS_PRIM(C, RT_HIT_BOX)) {                                                               // Box.cs:147-182
             const float4* b = sc.boxes + 6 * idx;
             float k; BoxSolve bs;
             box_core(b, r, c.k, c.k, false, k, bs);     // same t1/s as the accepted test; the range only selects near/far
@@ -595,7 +622,7 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
             h.n = normalize(nrm);
             h.outside = dot(r.d, nrm) < 0.0f;
         } break;
-        case RT_HIT_CAPSULE: {                                                           // Capsule.cs:114-140, CapNormal :186-191
+        case RT_HIT_CAPSULE: if constexpr (RT_HAS_PRIM(C, RT_HIT_CAPSULE)) {                                                           // Capsule.cs:114-140, CapNormal :186-191
             const float4* cp = sc.capsules + 5 * idx;
             float4 c0 = cp[0], c1 = cp[1];
             f3 P1 = mk3(c0.x, c0.y, c0.z), P2 = mk3(c1.x, c1.y, c1.z); float radius = c0.w;
@@ -613,12 +640,12 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                 h.v = (q.z - lo) / (hi - lo);
             }
         } break;
-        case RT_HIT_CYLINDER: {                                                          // Cylinder.cs:100-104
+        case RT_HIT_CYLINDER: if constexpr (RT_HAS_PRIM(C, RT_HIT_CYLINDER)) {                                                          // Cylinder.cs:100-104
             float k; f3 nrm = mk3(0, 0, 0);
             try_cylinder(sc.cylinders + 2 * idx, r, c.k, c.k, k, nrm, false);
             h.n = nrm; h.outside = !(dot(r.d, nrm) > 0.0f);
         } break;
-        case RT_HIT_MEDIUM: {                                                            // ConstantDensityMedium.cs:61-67
+        case RT_HIT_MEDIUM: if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {                                                            // ConstantDensityMedium.cs:61-67
             float4 u = rng_draw(key, depth, SLOT_MEDIUM, c.obj);
             h.wp = point_at(r.o, r.d, c.aux);         // sic: measured from the ray origin
             h.n = on_unit_sphere(u.y, u.z, u.w);
@@ -681,9 +708,10 @@ RT_FN float marble_noise(float x, float y, float z) {
     return value;
 }
 
+template <class C>
 RT_FN col3 texture_colour(const SceneDev& sc, uint32_t tex, f3 wp) {
     const rt_texture* t = sc.textures + tex;
-    if (t->type == RT_TEX_SOLID) return mkc(t->f[0], t->f[1], t->f[2]);                 // SolidColourTexture.cs:14
+    if (!RT_HAS_TEX(C, RT_TEX_MARBLE) || t->type == RT_TEX_SOLID) return mkc(t->f[0], t->f[1], t->f[2]);                 // SolidColourTexture.cs:14
     float scale = t->f[0], noiseScale = t->f[1], noiseStrength = t->f[2], dropoff = t->f[3];   // MarbleTexture.cs:38-48
     float x = wp.x / scale, y = wp.y / scale, z = wp.z / scale;
     float tt = x + y + z;
@@ -722,10 +750,12 @@ RT_FN float attenuation(const rt_light* l, float x) {                           
     }
 }
 // GetShadowRayForHit: PointLight.cs:7, DiffuseSphereLight.cs:85-139, DiffuseShapedLight.cs:67-103
+template <class C>
 RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f3 normal, const RngKey& key, uint32_t depth, uint32_t slotBase, uint32_t sub) {
     f3 pos = mk3(l->position[0], l->position[1], l->position[2]);
-    if (l->type == RT_LIGHT_POINT) return default_shadow_ray(wp, pos);
-    if (l->type == RT_LIGHT_DIFFUSE_SPHERE) {
+    // (the host picks a kernel variant whose Cfg covers every light type in the scene, so a type outside C::lights cannot occur)
+    if (l->type == RT_LIGHT_POINT || C::lights == (1u << RT_LIGHT_POINT)) return default_shadow_ray(wp, pos);
+    if (RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SPHERE) && (l->type == RT_LIGHT_DIFFUSE_SPHERE || !RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SHAPED))) {
         float R = l->diffusion_radius;
         if (distance(wp, pos) <= R * 1.01f) {
             for (uint32_t i = 0; i < 1000; i++) {
@@ -752,13 +782,14 @@ RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f
         return default_shadow_ray(wp, pos + (randDir * R));
     }
     // DiffuseShapedLight
+    if constexpr (!RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SHAPED)) return default_shadow_ray(wp, pos);
     f3 mn = mk3(l->shape_aabb_min[0], l->shape_aabb_min[1], l->shape_aabb_min[2]), mx = mk3(l->shape_aabb_max[0], l->shape_aabb_max[1], l->shape_aabb_max[2]);
     for (uint32_t i = 0; i < 1000; i++) {
         float4 u = rng_draw(key, depth, slotBase + i, sub);
         f3 p2 = mk3(lerpf(mn.x, mx.x, u.x), lerpf(mn.y, mx.y, u.y), lerpf(mn.z, mx.z, u.z));
         Ray ry; ry.o = wp; ry.d = normalize(p2 - wp);
         float k;
-        if (try_object_solid(sc, l->shape_type, l->shape_index, ry, 0.0001f, __builtin_inff(), k)) {
+        if (try_object_solid<C>(sc, l->shape_type, l->shape_index, ry, 0.0001f, __builtin_inff(), k)) {
             ShadowRay s; s.r = ry; s.kMin = 0.001f; s.kMax = k - 0.001f; return s;
         }
     }

@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
 
 extern __shared__ int lds_stack[];   // [stack_depth][BLOCK]
 
+template <class C>
 __global__ void __launch_bounds__(BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const uint32_t* q = rd.queue[depth & 1];
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest(SceneDev sc, RenderDev rd, ui
         Ray r = load_ray(rd, id);
         RngKey key = path_key(rd, id);
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        Closest c = closest_hit(sc, r, rd.k_min, rd.k_max, key, depth, lds_stack + threadIdx.x, BLOCK, cnt);
+        Closest c = closest_hit<C>(sc, r, rd.k_min, rd.k_max, key, depth, lds_stack + threadIdx.x, BLOCK, cnt);
         rd.hit_k[id] = c.k; rd.hit_obj[id] = c.obj; rd.hit_aux[id] = c.aux;
         rays++; nodes += cnt.nodes; prims += cnt.prims;
     }
@@ -127,6 +128,7 @@ RT_FN uint32_t block_scan_pair(uint32_t v, uint32_t* wave_tot /* [BLOCK/64] in L
     return before + inc - v;
 }
 
+template <class C>
 __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const uint32_t* q = rd.queue[depth & 1];
@@ -155,25 +157,25 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                 if (depth > 0) hist_miss++;                                              // RenderJob.cs:458: maxDepthReached = depth - 1
             } else {
                 RngKey key = path_key(rd, id);
-                HitRec h = finalize_hit<false>(sc, r, c, key, depth);
+                HitRec h = finalize_hit<C, false>(sc, r, c, key, depth);
                 const rt_material* m = sc.materials + h.mat;
                 uint32_t prev = rd.prev_mat[id], first = rd.first_mat[id];
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
-                Ray nr; nr.o = h.wp;
+                Ray nr; nr.o = h.wp; nr.d = r.d;
                 col3 a = mkc(1, 1, 1);        // multiplier of the future colour
                 col3 W = mkc(0, 0, 0);        // weight of the light sum
                 bool lights = false;
                 switch (m->type) {
-                    case RT_MAT_STANDARD: {                                              // StandardMaterial.cs:45-60
+                    case RT_MAT_STANDARD: if constexpr (RT_HAS_MAT(C, RT_MAT_STANDARD)) {                                            // StandardMaterial.cs:45-60
                         f3 diffuse = on_unit_sphere(u.x, u.y, u.z);
                         if (dot(diffuse, h.n) < 0) diffuse = diffuse * -1.0f;
                         f3 refl = reflect(r.d, h.n);
                         nr.d = normalize(normalize(lerp3(refl, diffuse, m->f[0])));
-                        a = texture_colour(sc, m->tex[0], h.wp);
-                        L = L + (T * texture_colour(sc, m->tex[1], h.wp));
+                        a = texture_colour<C>(sc, m->tex[0], h.wp);
+                        L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
                         W = T * a; lights = true;
                     } break;
-                    case RT_MAT_PHONG: {                                                 // PhongMaterial.cs:18-76
+                    case RT_MAT_PHONG: if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                                               // PhongMaterial.cs:18-76
                         f3 dir = on_unit_sphere(u.x, u.y, u.z);
                         if (dot(dir, h.n) < 0) dir = dir * -1.0f;
                         nr.d = normalize(dir);
@@ -185,12 +187,12 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                         W = T; lights = true;
                         rd.sh_in[0][id] = r.d.x; rd.sh_in[1][id] = r.d.y; rd.sh_in[2][id] = r.d.z;
                     } break;
-                    case RT_MAT_VOLUMETRIC: {                                            // ConstantDensityMedium.cs:102-129
+                    case RT_MAT_VOLUMETRIC: if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) {                                          // ConstantDensityMedium.cs:102-129
                         nr.d = normalize(on_unit_sphere(u.x, u.y, u.z));
                         float pw = m->f[3] * h.shader;
                         a = mkc(powf(m->f[0], pw), powf(m->f[1], pw), powf(m->f[2], pw));
                     } break;
-                    default: {                                                           // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
+                    default: if constexpr (RT_HAS_MAT(C, RT_MAT_REFRACTIVE) || RT_HAS_MAT(C, RT_MAT_EMISSIVE_REFRACTIVE)) {                                                         // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
                         f3 ud = normalize(r.d);
                         float cosT = minf_net(dot(-ud, h.n), 1.0f);
                         float sinT = sqrtf(1.0f - (cosT * cosT));
@@ -213,11 +215,11 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                             out = normalize((sqrtf((1 - powf(ratio, 2.0f)) * (1 - powf(nd, 2.0f))) * h.n) + (ratio * (ud - (nd * h.n))));
                         }
                         nr.d = normalize(out);
-                        a = texture_colour(sc, m->tex[0], h.wp);
+                        a = texture_colour<C>(sc, m->tex[0], h.wp);
                         W = T * a; lights = true;
                         if (m->type == RT_MAT_EMISSIVE_REFRACTIVE) {
                             bool emit = (m->flags & RT_MAT_FLAG_DIRECT_EMISSION) || !(depth == 0 || (depth == 1 && first == h.mat));
-                            if (emit) L = L + (T * texture_colour(sc, m->tex[1], h.wp));
+                            if (emit) L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
                         }
                     } break;
                 }
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
 }
 
 // Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
+template <class C>
 __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.sqcount[depth];
     unsigned long long rays = 0, nodes = 0, prims = 0;
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
         f3 nrm = mk3(rd.sh_n[0][id], rd.sh_n[1][id], rd.sh_n[2][id]);
         col3 W = mkc(rd.sh_w[0][id], rd.sh_w[1][id], rd.sh_w[2][id]);
         const rt_material* m = sc.materials + sc.obj_material[rd.hit_obj[id]];   // hit_obj still holds this bounce's hit
-        const bool phong = m->type == RT_MAT_PHONG;
+        const bool phong = RT_HAS_MAT(C, RT_MAT_PHONG) && m->type == RT_MAT_PHONG;
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0);
         f3 in = phong ? mk3(rd.sh_in[0][id], rd.sh_in[1][id], rd.sh_in[2][id]) : mk3(0, 0, 0);
@@ -285,10 +288,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
             for (uint32_t li = 0; li < sc.n_lights; li++) {
                 const rt_light* l = sc.lights + li;
                 uint32_t sub = s * sc.n_lights + li;
-                ShadowRay sr = light_shadow_ray(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
+                ShadowRay sr = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
                 rays++;
                 col3 c = mkc(0, 0, 0);
-                if (!any_hit(sc, sr.r, sr.kMin, sr.kMax, stack, BLOCK, cnt)) {
+                if (!any_hit<C>(sc, sr.r, sr.kMin, sr.kMax, stack, BLOCK, cnt)) {
                     if (!(sr.kMax > l->cutoff_radius)) {
                         float scale = attenuation(l, sr.kMax / l->attenuation_radius);
                         scale = maxf_net(scale, 0);
@@ -297,9 +300,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
                 }
                 if (!phong) sum = sum + c;
                 else {                                                                    // PhongMaterial.cs:42-56
-                    ShadowRay s2 = light_shadow_ray(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
+                    ShadowRay s2 = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
-                    col3 c2 = any_hit(sc, s2.r, s2.kMin, s2.kMax, stack, BLOCK, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
+                    col3 c2 = any_hit<C>(sc, s2.r, s2.kMin, s2.kMax, stack, BLOCK, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
                     f3 rl = reflect(s2.r.d, -nrm);
                     float sd = fabsf(dot(in, rl));
                     spec_sum = spec_sum + (c2 * powf(sd, powf(2.0f, m->f[9])));
@@ -346,16 +349,17 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t 
 }
 
 // Parity hooks: one thread per caller-supplied ray.
+template <class C>
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         RngKey key = make_key(seed, (uint32_t)i, 0);
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        Closest c = closest_hit(sc, r, kMin, kMax, key, 0, lds_stack + threadIdx.x, BLOCK, cnt);
+        Closest c = closest_hit<C>(sc, r, kMin, kMax, key, 0, lds_stack + threadIdx.x, BLOCK, cnt);
         rt_hit h = {};
         h.object = RT_NO_HIT; h.material = RT_NO_HIT;
         if (c.obj != RT_NO_HIT) {
-            HitRec hr = finalize_hit<true>(sc, r, c, key, 0);
+            HitRec hr = finalize_hit<C, true>(sc, r, c, key, 0);
             h.k = hr.k; h.object = hr.obj; h.material = hr.mat;
             h.normal[0] = hr.n.x; h.normal[1] = hr.n.y; h.normal[2] = hr.n.z;
             h.uv[0] = hr.u; h.uv[1] = hr.v;
@@ -366,12 +370,38 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(SceneDev sc, const rt_r
     }
 }
 
+template <class C>
 __global__ void __launch_bounds__(BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        occluded[i] = any_hit(sc, r, kMin[i], kMax[i], lds_stack + threadIdx.x, BLOCK, cnt) ? 1 : 0;
+        occluded[i] = any_hit<C>(sc, r, kMin[i], kMax[i], lds_stack + threadIdx.x, BLOCK, cnt) ? 1 : 0;
     }
+}
+
+
+// ---- kernel variants (Cfg in rt_device.h).  The host (rt_lib.hip) picks the first one whose masks cover the scene. ----
+constexpr uint32_t pbit(int t) { return 1u << t; }
+using CfgSpheres = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_INFINITE_PLANE),
+                       pbit(RT_MAT_STANDARD) | pbit(RT_MAT_REFRACTIVE) | pbit(RT_MAT_EMISSIVE_REFRACTIVE), pbit(RT_TEX_SOLID),
+                       pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Night Spheres, RtInAWeekend, many-lights
+using CfgMesh    = Cfg<pbit(RT_HIT_TRIANGLE) | pbit(RT_HIT_INFINITE_PLANE), pbit(RT_MAT_STANDARD), pbit(RT_TEX_SOLID), pbit(RT_LIGHT_POINT)>;
+using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_PLANE) | pbit(RT_HIT_XZ_PLANE) | pbit(RT_HIT_YZ_PLANE) | pbit(RT_HIT_QUAD),
+                       pbit(RT_MAT_STANDARD) | pbit(RT_MAT_REFRACTIVE) | pbit(RT_MAT_EMISSIVE_REFRACTIVE), pbit(RT_TEX_SOLID),
+                       pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
+using CfgAll     = Cfg<(1u << RT_HIT_TYPE_COUNT) - 1, 0x1Fu, 0x3u, 0x7u>;
+
+struct KernelSet {
+    const char* name;
+    uint32_t prims, mats, texs, lights;
+    void (*closest)(SceneDev, RenderDev, uint32_t);
+    void (*shade)(SceneDev, RenderDev, uint32_t);
+    void (*shadow)(SceneDev, RenderDev, uint32_t);
+    void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
+    void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+};
+template <class C> constexpr KernelSet make_kernel_set(const char* name) {
+    return KernelSet{name, C::prims, C::mats, C::texs, C::lights, k_closest<C>, k_shade<C>, k_shadow<C>, k_trace_closest<C>, k_trace_any<C>};
 }
 
 } // namespace rtd

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -61,8 +62,17 @@ inline bool finite3(const float* a) { return std::isfinite(a[0]) && std::isfinit
 
 } // namespace
 
+namespace {
+// most specific first; the last entry covers everything
+const KernelSet g_kernel_sets[] = {
+    make_kernel_set<CfgSpheres>("spheres"), make_kernel_set<CfgMesh>("mesh"), make_kernel_set<CfgBoxes>("boxes"), make_kernel_set<CfgAll>("generic"),
+};
+constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
+} // namespace
+
 struct rt_scene {
     int device = 0;
+    const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
     SceneDev dev{};
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t n_objects = 0, n_lights = 0;
@@ -71,17 +81,32 @@ struct rt_scene {
            media_rec, materials, textures, lights;
 };
 
+// One batch in flight: its own path state, counters and stream.  Batches are independent until they add into the image
+// sums, so a few of them run concurrently: the deep bounces of one batch (few paths, latency-bound launches) overlap the
+// wide first bounces of the next.  The adds into the sums stay in batch order (event chain), so results do not depend on it.
+struct Slot {
+    RenderDev rd{};
+    hipStream_t stream = nullptr;
+    DevBuf f32_pool, u32_pool, counters;
+};
+constexpr int MAX_SLOTS = 4;
+
 struct rt_render {
     rt_scene* scene = nullptr;
     rt_render_opts opts{};
-    RenderDev rd{};
+    RenderDev rd{};                  // slot 0's view (shared fields)
     uint32_t passes_per_batch = 1;
     size_t max_paths = 0;
-    hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t stream = nullptr; bool own_stream = false;     // the stream results are ordered on (slot 0's)
+    int n_slots = 1;
+    Slot slots[MAX_SLOTS];
+    hipEvent_t ev_acc[MAX_SLOTS] = {};      // recorded after a slot's k_accumulate
+    hipEvent_t ev_fork = nullptr;
+    uint64_t batches_enqueued = 0;
     float* accum = nullptr; bool own_accum = false;
     uint32_t sample_count = 0;
     uint64_t passes_rendered = 0;
-    DevBuf f32_pool, u32_pool, counters, stats, accum_buf, rgb;
+    DevBuf stats, accum_buf, rgb;
     std::vector<unsigned long long> stats_host;
     // per-kernel event timing (rt_render_set_profiling)
     bool profiling = false;
@@ -94,19 +119,19 @@ struct rt_render {
 namespace {
 // Brackets one launch with two event records when profiling is on.
 struct Timed {
-    rt_render* r; int cls; hipEvent_t a = nullptr, b = nullptr;
+    rt_render* r; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     static hipEvent_t get(rt_render* r) {
         if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
         hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
     }
-    Timed(rt_render* r_, int cls_) : r(r_), cls(cls_) {
+    Timed(rt_render* r_, int cls_, hipStream_t st_ = nullptr) : r(r_), cls(cls_), st(st_ ? st_ : r_->stream) {
         if (!r->profiling) return;
         a = get(r); b = get(r);
-        if (a) (void)hipEventRecord(a, r->stream);
+        if (a) (void)hipEventRecord(a, st);
     }
     ~Timed() {
         if (!r->profiling) return;
-        if (b) (void)hipEventRecord(b, r->stream);
+        if (b) (void)hipEventRecord(b, st);
         if (a && b) r->stamps.push_back({cls, a, b});
     }
 };
@@ -204,6 +229,21 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     rtbvh::BuildResult bvh = rtbvh::build(boxes, box_obj);
 
+    // what the scene contains -> the most specific kernel variant that covers it (RT_HIP_VARIANT=generic forces the general one; test knob)
+    uint32_t m_prims = 0, m_mats = 0, m_texs = 0, m_lights = 0;
+    for (uint32_t i = 0; i < d->n_objects; i++) m_prims |= 1u << d->objects[i].type;
+    for (uint32_t i = 0; i < d->n_media; i++) m_prims |= 1u << d->media[i].boundary_type;
+    for (uint32_t i = 0; i < d->n_lights; i++) { m_lights |= 1u << d->lights[i].type; if (d->lights[i].type == RT_LIGHT_DIFFUSE_SHAPED) m_prims |= 1u << d->lights[i].shape_type; }
+    for (uint32_t i = 0; i < d->n_materials; i++) m_mats |= 1u << d->materials[i].type;
+    for (uint32_t i = 0; i < d->n_textures; i++) m_texs |= 1u << d->textures[i].type;
+    const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
+    const char* force = getenv("RT_HIP_VARIANT");
+    if (!(force && !strcmp(force, "generic")))
+        for (int i = 0; i < N_KERNEL_SETS; i++) {
+            const KernelSet& k = g_kernel_sets[i];
+            if (!(m_prims & ~k.prims) && !(m_mats & ~k.mats) && !(m_texs & ~k.texs) && !(m_lights & ~k.lights)) { ks = &k; break; }
+        }
+
     // float4-aligned records
     auto pack = [](const float* src, size_t n_rec, size_t floats_in, size_t quads_out) {
         std::vector<float4> v(n_rec * quads_out, make_float4(0, 0, 0, 0));
@@ -257,7 +297,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
 
     auto s = std::make_unique<rt_scene>();
-    s->device = device;
+    s->device = device; s->ks = ks;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -321,7 +361,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, f
     DevBuf dr, dh;
     HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dh.alloc(n * sizeof(rt_hit)));
     HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
+    hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
@@ -338,7 +378,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d0.p, k_min, n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d1.p, k_max, n * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
+    hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(occluded, dout.p, n, hipMemcpyDeviceToHost));
@@ -376,12 +416,10 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->stream) r->stream = (hipStream_t)o->stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
 
-    const int n_f32 = 6 + 3 + 3 + 2 + 12;     // ray, thr, rad, hit_k, hit_aux, shadow payload
-    const int n_u32 = 1 + 2 + 2 + 1;          // hit_obj, prev/first mat, 2 queues, shadow queue
-    HIP_TRY(r->f32_pool.alloc(P * n_f32 * sizeof(float)));
-    HIP_TRY(r->u32_pool.alloc(P * n_u32 * sizeof(uint32_t)));
-    const uint32_t n_cnt = o->max_bounce_depth + 2;
-    HIP_TRY(r->counters.alloc(2 * n_cnt * sizeof(uint32_t)));
+    // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob); one when the whole job is a single batch
+    int n_slots = 2;
+    if (const char* e = getenv("RT_HIP_SLOTS")) n_slots = std::max(1, std::min(MAX_SLOTS, atoi(e)));
+    r->n_slots = n_slots;
     HIP_TRY(r->stats.alloc(ST_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(r->stats.p, 0, r->stats.bytes, r->stream));
     HIP_TRY(r->rgb.alloc(n_pixels * 3));
@@ -392,25 +430,39 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
         r->accum = r->accum_buf.as<float>(); r->own_accum = true;
     }
     HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
 
-    RenderDev& rd = r->rd;
-    float* f = r->f32_pool.as<float>(); uint32_t* u = r->u32_pool.as<uint32_t>();
-    auto nf = [&]() { float* p = f; f += P; return p; };
-    auto nu = [&]() { uint32_t* p = u; u += P; return p; };
-    for (int i = 0; i < 6; i++) rd.ray[i] = nf();
-    for (int i = 0; i < 3; i++) rd.thr[i] = nf();
-    for (int i = 0; i < 3; i++) rd.rad[i] = nf();
-    rd.hit_k = nf(); rd.hit_aux = nf();
-    for (int i = 0; i < 3; i++) rd.sh_wp[i] = nf();
-    for (int i = 0; i < 3; i++) rd.sh_n[i] = nf();
-    for (int i = 0; i < 3; i++) rd.sh_w[i] = nf();
-    for (int i = 0; i < 3; i++) rd.sh_in[i] = nf();
-    rd.hit_obj = nu(); rd.prev_mat = nu(); rd.first_mat = nu(); rd.queue[0] = nu(); rd.queue[1] = nu(); rd.squeue = nu();
-    rd.qcount = r->counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
-    rd.stats = r->stats.as<unsigned long long>();
-    rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
-    rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
-    rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+    const int n_f32 = 6 + 3 + 3 + 2 + 12;     // ray, thr, rad, hit_k, hit_aux, shadow payload
+    const int n_u32 = 1 + 2 + 2 + 1;          // hit_obj, prev/first mat, 2 queues, shadow queue
+    const uint32_t n_cnt = o->max_bounce_depth + 2;
+    for (int si = 0; si < n_slots; si++) {
+        Slot& sl = r->slots[si];
+        if (si == 0) sl.stream = r->stream;
+        else HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_acc[si], hipEventDisableTiming));
+        HIP_TRY(sl.f32_pool.alloc(P * n_f32 * sizeof(float)));
+        HIP_TRY(sl.u32_pool.alloc(P * n_u32 * sizeof(uint32_t)));
+        HIP_TRY(sl.counters.alloc(2 * n_cnt * sizeof(uint32_t)));
+        RenderDev& rd = sl.rd;
+        float* f = sl.f32_pool.as<float>(); uint32_t* u = sl.u32_pool.as<uint32_t>();
+        auto nf = [&]() { float* p = f; f += P; return p; };
+        auto nu = [&]() { uint32_t* p = u; u += P; return p; };
+        for (int i = 0; i < 6; i++) rd.ray[i] = nf();
+        for (int i = 0; i < 3; i++) rd.thr[i] = nf();
+        for (int i = 0; i < 3; i++) rd.rad[i] = nf();
+        rd.hit_k = nf(); rd.hit_aux = nf();
+        for (int i = 0; i < 3; i++) rd.sh_wp[i] = nf();
+        for (int i = 0; i < 3; i++) rd.sh_n[i] = nf();
+        for (int i = 0; i < 3; i++) rd.sh_w[i] = nf();
+        for (int i = 0; i < 3; i++) rd.sh_in[i] = nf();
+        rd.hit_obj = nu(); rd.prev_mat = nu(); rd.first_mat = nu(); rd.queue[0] = nu(); rd.queue[1] = nu(); rd.squeue = nu();
+        rd.qcount = sl.counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
+        rd.stats = r->stats.as<unsigned long long>();
+        rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
+        rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
+        rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+    }
+    r->rd = r->slots[0].rd;
     r->stats_host.assign(ST_COUNT, 0);
     *out = r.release();
     return RT_OK;
@@ -419,32 +471,43 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
 int rt_render_destroy(rt_render* r) {
     if (!r) return RT_OK;
     DeviceGuard guard(r->scene->device);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (int si = 0; si < r->n_slots; si++) if (r->slots[si].stream) (void)hipStreamSynchronize(r->slots[si].stream);
     collect_stamps(r);
     for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
+    for (int si = 0; si < r->n_slots; si++) {
+        if (r->ev_acc[si]) (void)hipEventDestroy(r->ev_acc[si]);
+        if (si > 0 && r->slots[si].stream) (void)hipStreamDestroy(r->slots[si].stream);
+    }
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
     return RT_OK;
 }
 
-// One wavefront batch of `np` passes starting at pass `first` (stride `stride`); enqueues only.
-static int enqueue_batch(rt_render* r, uint64_t first, uint32_t np, uint32_t stride) {
+// One wavefront batch of `np` passes starting at pass `first` (stride `stride`) on slot `si`; enqueues only.
+static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint32_t stride) {
     rt_scene* s = r->scene;
-    RenderDev rd = r->rd;
+    Slot& sl = r->slots[si];
+    RenderDev rd = sl.rd;
     rd.n_paths = rd.n_pixels * np; rd.first_pass = first; rd.pass_stride = stride;
-    hipStream_t st = r->stream;
+    hipStream_t st = sl.stream;
+    const KernelSet* ks = s->ks;
     const uint32_t n_cnt = r->opts.max_bounce_depth + 2;
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
     const size_t lds = stack_bytes(s);
-    { Timed t(r, RT_K_RAYGEN); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
+    { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= r->opts.max_bounce_depth; depth++) {
-        { Timed t(r, RT_K_CLOSEST); hipLaunchKernelGGL(k_closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
-        { Timed t(r, RT_K_SHADE); hipLaunchKernelGGL(k_shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
-        if (s->n_lights) { Timed t(r, RT_K_SHADOW); hipLaunchKernelGGL(k_shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+        { Timed t(r, RT_K_CLOSEST, st); hipLaunchKernelGGL(ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+        { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(ks->shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
+        if (s->n_lights) { Timed t(r, RT_K_SHADOW, st); hipLaunchKernelGGL(ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
-    { Timed t(r, RT_K_ACCUMULATE); hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, rd.n_pixels, 8)), dim3(BLOCK), 0, st, rd, r->accum, np); }
+    // the adds into the image sums happen in batch order whatever slot a batch ran on
+    if (r->batches_enqueued > 0 && r->n_slots > 1) HIP_TRY(hipStreamWaitEvent(st, r->ev_acc[(si + r->n_slots - 1) % r->n_slots], 0));
+    { Timed t(r, RT_K_ACCUMULATE, st); hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, rd.n_pixels, 8)), dim3(BLOCK), 0, st, rd, r->accum, np); }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(r->ev_acc[si], st));
+    r->batches_enqueued++;
     return RT_OK;
 }
 
@@ -452,14 +515,29 @@ int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint3
     if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_passes: null handle");
     if (pass_stride < 1) pass_stride = 1;
     DeviceGuard guard(r->scene->device);
+    // per-kernel event timing wants kernels that do not overlap: one slot while profiling
+    const int n_slots = r->profiling ? 1 : r->n_slots;
+    // the other slots start after whatever the caller already queued on the main stream
+    if (n_slots > 1) {
+        HIP_TRY(hipEventRecord(r->ev_fork, r->stream));
+        for (int si = 1; si < n_slots; si++) HIP_TRY(hipStreamWaitEvent(r->slots[si].stream, r->ev_fork, 0));
+    }
     uint32_t done = 0;
+    int last_slot = 0;
     while (done < n_passes) {
         uint32_t np = std::min(r->passes_per_batch, n_passes - done);
-        int rc = enqueue_batch(r, first_pass + (uint64_t)done * pass_stride, np, pass_stride);
+        // slot = batch number mod slots, so that the accumulate chain (slot i waits for slot i-1) follows the batch order
+        int si = n_slots > 1 ? (int)(r->batches_enqueued % (uint64_t)r->n_slots) : 0;
+        if (si >= n_slots) si = 0;
+        int rc = enqueue_batch(r, si, first_pass + (uint64_t)done * pass_stride, np, pass_stride);
         if (rc) return rc;
+        last_slot = si;
         done += np;
     }
+    // join: the main stream continues after the last batch's accumulate (which itself follows all earlier ones)
+    if (last_slot != 0) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_acc[last_slot], 0));
     HIP_TRY(hipStreamSynchronize(r->stream));
+    for (int si = 1; si < r->n_slots; si++) HIP_TRY(hipStreamSynchronize(r->slots[si].stream));
     collect_stamps(r);
     r->sample_count += n_passes; r->passes_rendered += n_passes;
     return RT_OK;
