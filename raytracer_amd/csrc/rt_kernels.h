@@ -1,13 +1,15 @@
 // rt_kernels.h — the wavefront trace kernels (gfx950).
 //
-// One batch = P paths = (pixels) x (passes in the batch).  Path state lives in SoA arrays indexed by path id;
-// queues hold the ids of the paths still alive at the current bounce.  Per bounce:
-//   k_closest : queue -> closest hit (BVH traversal, per-lane stack in LDS)            RenderJob.cs:581-617
-//   k_shade   : hit/miss -> sky, scatter, affine colour terms, shadow requests,
-//               survivors compacted into the next queue with a wave ballot             RenderJob.cs:413-451, materials
-//   k_shadow  : one thread per shaded hit, LightSampleCountHint x |lights| any-hit rays Material.cs:30-45, SimpleLightBase.cs:22-40
-// then k_accumulate adds the finished radiance into the image sums in pass order       RenderJob.cs:626-647
-// and k_resolve makes RGB24                                                             RenderJob.cs:646-654.
+// One batch = P paths = (pixels) x (passes in the batch).  The paths alive at a bounce are DENSE: their state sits at
+// queue positions 0..n-1 of a ping-pong pair of float4 arrays, and the survivors of a bounce are compacted into the other
+// half — every state access is a coalesced 16-B-per-lane load or store, whatever fraction of the batch is still alive.
+// Per bounce:
+//   k_closest : position j -> closest hit (BVH traversal, per-lane stack in LDS)            RenderJob.cs:581-617
+//   k_shade   : hit/miss -> sky, scatter, affine colour terms, shadow requests; survivors
+//               and shadow requests get their output positions from one block scan          RenderJob.cs:413-451, materials
+//   k_shadow  : one thread per shaded hit, LightSampleCountHint x |lights| any-hit rays      Material.cs:30-45, SimpleLightBase.cs:22-40
+// A path that ends writes its radiance to out[path id]; k_accumulate adds those into the image sums in pass order
+// (RenderJob.cs:626-647) and k_resolve makes RGB24 (RenderJob.cs:646-654).
 //
 // The reference walks the hits backwards and lets each material transform the "future" colour
 // (RenderJob.cs:461-487).  Every builtin CalculateColour is affine in that colour, final = a*future + c, so
@@ -24,15 +26,17 @@ enum StatSlot : int {
     ST_DEPTH0, ST_COUNT = ST_DEPTH0 + RT_DEPTH_HIST_SIZE
 };
 
+// Path state at queue position j (4 x float4 = 64 B):
+//   g0 = (origin.xyz, dir.x)  g1 = (dir.y, dir.z, T.r, T.g)  g2 = (T.b, L.r, L.g, L.b)  g3 = (path id, prev material, first material, -) as bits
+// Shadow request at shadow-queue position p (3 x float4, + 1 for Phong):
+//   h0 = (hit point.xyz, normal.x)  h1 = (normal.y, normal.z, W.r, W.g)  h2 = (W.b, path id, dst, hit object) as bits   h3 = (incoming dir.xyz, -)
+//   dst = position in the NEXT state whose L receives the light sum, or RT_NO_HIT when the path ended (then out[path id] does)
 struct RenderDev {
-    float* ray[6];            // origin xyz, direction xyz
-    float* thr[3];            // T
-    float* rad[3];            // L
-    float* hit_k; uint32_t* hit_obj; float* hit_aux;
-    uint32_t* prev_mat; uint32_t* first_mat;
-    uint32_t* queue[2];       // ping-pong path-id queues
-    uint32_t* squeue;         // shadow requests (path ids)
-    float* sh_wp[3]; float* sh_n[3]; float* sh_w[3]; float* sh_in[3];   // shadow request payload, by path id
+    float4* st[2][4];
+    float2* hit;              // (K, object id bits) by queue position
+    float*  hit_aux;          // HitRecord.ShaderData (media only) by queue position
+    float4* out;              // final radiance by path id
+    float4* sh[4];
     uint32_t* qcount;         // [max_depth + 2] alive paths per bounce
     uint32_t* sqcount;        // [max_depth + 2] shadow requests per bounce
     unsigned long long* stats;// [ST_COUNT]
@@ -60,12 +64,6 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
     uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
     return make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
 }
-RT_FN Ray load_ray(const RenderDev& rd, uint32_t id) {
-    Ray r; r.o = mk3(rd.ray[0][id], rd.ray[1][id], rd.ray[2][id]); r.d = mk3(rd.ray[3][id], rd.ray[4][id], rd.ray[5][id]); return r;
-}
-RT_FN void store_ray(const RenderDev& rd, uint32_t id, Ray r) {
-    rd.ray[0][id] = r.o.x; rd.ray[1][id] = r.o.y; rd.ray[2][id] = r.o.z; rd.ray[3][id] = r.d.x; rd.ray[4][id] = r.d.y; rd.ray[5][id] = r.d.z;
-}
 
 // RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay
 __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
@@ -78,11 +76,10 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
         s += plus_minus_one(u.x) * 0.5f;
         t += plus_minus_one(u.y) * 0.5f;
         Ray r = camera_ray(sc.camera, s / (float)rd.width, t / (float)rd.height, u.z, u.w);
-        store_ray(rd, id, r);
-        rd.thr[0][id] = 1.0f; rd.thr[1][id] = 1.0f; rd.thr[2][id] = 1.0f;
-        rd.rad[0][id] = 0.0f; rd.rad[1][id] = 0.0f; rd.rad[2][id] = 0.0f;
-        rd.prev_mat[id] = RT_NO_HIT; rd.first_mat[id] = RT_NO_HIT;
-        rd.queue[0][id] = id;
+        rd.st[0][0][id] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+        rd.st[0][1][id] = make_float4(r.d.y, r.d.z, 1.0f, 1.0f);
+        rd.st[0][2][id] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        rd.st[0][3][id] = make_float4(__uint_as_float(id), __uint_as_float(RT_NO_HIT), __uint_as_float(RT_NO_HIT), 0.0f);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = rd.n_paths;
 }
@@ -92,79 +89,100 @@ extern __shared__ int lds_stack[];   // [stack_depth][BLOCK]
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
-    const uint32_t* q = rd.queue[depth & 1];
+    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
     unsigned long long rays = 0, nodes = 0, prims = 0;
     for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
-        uint32_t id = q[j];
-        Ray r = load_ray(rd, id);
-        RngKey key = path_key(rd, id);
+        float4 a = g0[j], b = g1[j];
+        Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
+        RngKey key = make_key(0, 0, 0);
+        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, __float_as_uint(g3[j].x));     // only a medium draws random numbers
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         Closest c = closest_hit<C>(sc, r, rd.k_min, rd.k_max, key, depth, lds_stack + threadIdx.x, BLOCK, cnt);
-        rd.hit_k[id] = c.k; rd.hit_obj[id] = c.obj; rd.hit_aux[id] = c.aux;
+        rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
+        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
         rays++; nodes += cnt.nodes; prims += cnt.prims;
     }
     stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
 }
 
-// Block-level queue append.  A same-address returning atomic is serviced about every 10 ns chip-wide, so one
-// reservation per wave (260 k per 16.6 M paths) made k_shade 8x slower than its memory traffic; here every thread
-// shades SHADE_ITEMS paths, parks their ids (+2 flag bits) in LDS, and the block reserves its output ranges with ONE
-// atomic per queue per SHADE_ITEMS * BLOCK paths.
+// Output positions.  A same-address returning atomic is serviced about every 10 ns chip-wide, so a reservation per wave
+// (260 k per 16.6 M paths) made the kernel 8x slower than its memory traffic.  Whether a path survives and whether it asks
+// for light samples follows from its hit alone, so a block first reads the hit ids of SHADE_ITEMS x BLOCK positions, counts,
+// reserves both output ranges with ONE atomic each, and then shades; positions inside the tile keep the input order.
 constexpr int SHADE_ITEMS = 8;
-constexpr uint32_t FLAG_SURVIVE = 0x80000000u, FLAG_SHADOW = 0x40000000u, ID_MASK = 0x3FFFFFFFu;
-
-// exclusive scan over the block of a packed pair of 16-bit counts; returns this thread's offsets, block totals in `total`
-RT_FN uint32_t block_scan_pair(uint32_t v, uint32_t* wave_tot /* [BLOCK/64] in LDS */, uint32_t& total) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(inc, off, 64); if (lane >= (uint32_t)off) inc += t; }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < BLOCK / 64; w++) { uint32_t t = wave_tot[w]; all += t; if (w < wave) before += t; }
-    total = all;
-    return before + inc - v;
-}
 
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
-    const uint32_t* q = rd.queue[depth & 1];
-    uint32_t* qn = rd.queue[(depth + 1) & 1];
+    const int cur = depth & 1, nxt = cur ^ 1;
     unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0;
-    __shared__ uint32_t parked[SHADE_ITEMS * BLOCK];
-    __shared__ uint32_t wave_tot[BLOCK / 64];
+    __shared__ uint32_t wcnt[2][SHADE_ITEMS][BLOCK / 64];
     __shared__ uint32_t bases[2];
     constexpr uint32_t TILE = SHADE_ITEMS * BLOCK;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const bool can_survive = depth < rd.max_depth;
     for (uint32_t tile = blockIdx.x * TILE; tile < n; tile += gridDim.x * TILE) {     // uniform per block
-      uint32_t n_surv = 0, n_shad = 0;
+      uint32_t m_surv = 0, m_shad = 0;
+#pragma unroll
+      for (int item = 0; item < SHADE_ITEMS; item++) {
+          const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
+          bool hit = false, lit = false;
+          if (j < n) {
+              uint32_t obj = __float_as_uint(rd.hit[j].y);
+              hit = obj != RT_NO_HIT;
+              lit = hit && sc.n_lights > 0;
+              if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) { if (hit) lit = lit && sc.materials[sc.obj_material[obj]].type != RT_MAT_VOLUMETRIC; }
+          }
+          const bool surv = hit && can_survive;
+          unsigned long long bs = __ballot(surv), bl = __ballot(lit);
+          if (lane == 0) { wcnt[0][item][wave] = (uint32_t)__popcll(bs); wcnt[1][item][wave] = (uint32_t)__popcll(bl); }
+          m_surv |= (surv ? 1u : 0u) << item; m_shad |= (lit ? 1u : 0u) << item;
+      }
+      __syncthreads();
+      if (threadIdx.x < 2) {
+          uint32_t tot = 0;
+          for (int i = 0; i < SHADE_ITEMS; i++) for (int w = 0; w < BLOCK / 64; w++) tot += wcnt[threadIdx.x][i][w];
+          bases[threadIdx.x] = tot ? atomicAdd((threadIdx.x == 0 ? rd.qcount + depth + 1 : rd.sqcount + depth), tot) : 0u;
+      }
+      __syncthreads();
+      uint32_t row_s = bases[0], row_l = bases[1];
 #pragma unroll 1
       for (int item = 0; item < SHADE_ITEMS; item++) {
         const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
-        bool active = j < n, survive = false, shadow = false;
-        uint32_t id = 0;
-        if (active) {
-            id = q[j];
-            Ray r = load_ray(rd, id);
-            col3 T = mkc(rd.thr[0][id], rd.thr[1][id], rd.thr[2][id]);
-            col3 L = mkc(rd.rad[0][id], rd.rad[1][id], rd.rad[2][id]);
-            Closest c; c.k = rd.hit_k[id]; c.obj = rd.hit_obj[id]; c.aux = rd.hit_aux[id];
+        const bool survive = (m_surv >> item) & 1u, shadow = (m_shad >> item) & 1u;
+        // this path's output positions: rows before, waves before in the row, lanes before in the wave
+        uint32_t p0 = row_s, p1 = row_l;
+        for (uint32_t w = 0; w < BLOCK / 64; w++) {
+            uint32_t cs = wcnt[0][item][w], cl = wcnt[1][item][w];
+            if (w < wave) { p0 += cs; p1 += cl; }
+            row_s += cs; row_l += cl;
+        }
+        p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
+        p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
+        if (j < n) {
+            float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j], a3 = rd.st[cur][3][j];
+            Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
+            col3 T = mkc(a1.z, a1.w, a2.x);
+            col3 L = mkc(a2.y, a2.z, a2.w);
+            const uint32_t id = __float_as_uint(a3.x);
+            float2 hk = rd.hit[j];
+            Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
+            if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) c.aux = rd.hit_aux[j];
             if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450
                 L = L + (T * sky_colour(sc, r.d));
                 sky++; samples++;
                 if (depth > 0) hist_miss++;                                              // RenderJob.cs:458: maxDepthReached = depth - 1
+                rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
             } else {
                 RngKey key = path_key(rd, id);
                 HitRec h = finalize_hit<C, false>(sc, r, c, key, depth);
                 const rt_material* m = sc.materials + h.mat;
-                uint32_t prev = rd.prev_mat[id], first = rd.first_mat[id];
+                uint32_t prev = __float_as_uint(a3.y), first = __float_as_uint(a3.z);
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
                 Ray nr; nr.o = h.wp; nr.d = r.d;
                 col3 a = mkc(1, 1, 1);        // multiplier of the future colour
                 col3 W = mkc(0, 0, 0);        // weight of the light sum
-                bool lights = false;
                 switch (m->type) {
                     case RT_MAT_STANDARD: if constexpr (RT_HAS_MAT(C, RT_MAT_STANDARD)) {                                            // StandardMaterial.cs:45-60
                         f3 diffuse = on_unit_sphere(u.x, u.y, u.z);
@@ -173,7 +191,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                         nr.d = normalize(normalize(lerp3(refl, diffuse, m->f[0])));
                         a = texture_colour<C>(sc, m->tex[0], h.wp);
                         L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
-                        W = T * a; lights = true;
+                        W = T * a;
                     } break;
                     case RT_MAT_PHONG: if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                                               // PhongMaterial.cs:18-76
                         f3 dir = on_unit_sphere(u.x, u.y, u.z);
@@ -184,15 +202,15 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                         float sw = powf(fabsf(dot(r.d, rl)), powf(2.0f, m->f[9]));
                         L = L + (T * amb);
                         a = diff + (spec * sw);
-                        W = T; lights = true;
-                        rd.sh_in[0][id] = r.d.x; rd.sh_in[1][id] = r.d.y; rd.sh_in[2][id] = r.d.z;
+                        W = T;
+                        if (shadow) rd.sh[3][p1] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
                     } break;
                     case RT_MAT_VOLUMETRIC: if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) {                                          // ConstantDensityMedium.cs:102-129
                         nr.d = normalize(on_unit_sphere(u.x, u.y, u.z));
                         float pw = m->f[3] * h.shader;
                         a = mkc(powf(m->f[0], pw), powf(m->f[1], pw), powf(m->f[2], pw));
                     } break;
-                    default: if constexpr (RT_HAS_MAT(C, RT_MAT_REFRACTIVE) || RT_HAS_MAT(C, RT_MAT_EMISSIVE_REFRACTIVE)) {                                                         // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
+                    default: if constexpr (RT_HAS_MAT(C, RT_MAT_REFRACTIVE) || RT_HAS_MAT(C, RT_MAT_EMISSIVE_REFRACTIVE)) {            // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
                         f3 ud = normalize(r.d);
                         float cosT = minf_net(dot(-ud, h.n), 1.0f);
                         float sinT = sqrtf(1.0f - (cosT * cosT));
@@ -216,7 +234,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                         }
                         nr.d = normalize(out);
                         a = texture_colour<C>(sc, m->tex[0], h.wp);
-                        W = T * a; lights = true;
+                        W = T * a;
                         if (m->type == RT_MAT_EMISSIVE_REFRACTIVE) {
                             bool emit = (m->flags & RT_MAT_FLAG_DIRECT_EMISSION) || !(depth == 0 || (depth == 1 && first == h.mat));
                             if (emit) L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
@@ -224,43 +242,25 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                     } break;
                 }
                 scat++;                                                                   // RenderJob.cs:439
-                shadow = lights && sc.n_lights > 0;
                 if (shadow) {
-                    rd.sh_wp[0][id] = h.wp.x; rd.sh_wp[1][id] = h.wp.y; rd.sh_wp[2][id] = h.wp.z;
-                    rd.sh_n[0][id] = h.n.x; rd.sh_n[1][id] = h.n.y; rd.sh_n[2][id] = h.n.z;
-                    rd.sh_w[0][id] = W.r; rd.sh_w[1][id] = W.g; rd.sh_w[2][id] = W.b;
+                    rd.sh[0][p1] = make_float4(h.wp.x, h.wp.y, h.wp.z, h.n.x);
+                    rd.sh[1][p1] = make_float4(h.n.y, h.n.z, W.r, W.g);
+                    rd.sh[2][p1] = make_float4(W.b, __uint_as_float(id), __uint_as_float(survive ? p0 : RT_NO_HIT), __uint_as_float(c.obj));
                 }
                 T = T * a;
-                if (depth < rd.max_depth) {
-                    survive = true;
-                    store_ray(rd, id, nr);
-                    rd.thr[0][id] = T.r; rd.thr[1][id] = T.g; rd.thr[2][id] = T.b;
-                    rd.prev_mat[id] = h.mat;
-                    if (depth == 0) rd.first_mat[id] = h.mat;
+                if (survive) {
+                    rd.st[nxt][0][p0] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
+                    rd.st[nxt][1][p0] = make_float4(nr.d.y, nr.d.z, T.r, T.g);
+                    rd.st[nxt][2][p0] = make_float4(T.b, L.r, L.g, L.b);
+                    rd.st[nxt][3][p0] = make_float4(a3.x, __uint_as_float(h.mat), depth == 0 ? __uint_as_float(h.mat) : a3.z, 0.0f);
                 } else {                                                                  // RenderJob.cs:416-421: the next depth exceeds the limit, future = NoColour
                     limit++; samples++;                                                   // maxDepthReached = depth
+                    rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
                 }
             }
-            rd.rad[0][id] = L.r; rd.rad[1][id] = L.g; rd.rad[2][id] = L.b;
         }
-        parked[item * BLOCK + threadIdx.x] = id | (survive ? FLAG_SURVIVE : 0u) | (shadow ? FLAG_SHADOW : 0u);
-        n_surv += survive ? 1u : 0u; n_shad += shadow ? 1u : 0u;
       }
-      uint32_t total;
-      const uint32_t off = block_scan_pair(n_surv | (n_shad << 16), wave_tot, total);
-      if (threadIdx.x == 0) {
-          bases[0] = (total & 0xFFFFu) ? atomicAdd(rd.qcount + depth + 1, total & 0xFFFFu) : 0u;
-          bases[1] = (total >> 16) ? atomicAdd(rd.sqcount + depth, total >> 16) : 0u;
-      }
-      __syncthreads();
-      uint32_t p0 = bases[0] + (off & 0xFFFFu), p1 = bases[1] + (off >> 16);
-#pragma unroll 1
-      for (int item = 0; item < SHADE_ITEMS; item++) {
-          const uint32_t e = parked[item * BLOCK + threadIdx.x];
-          if (e & FLAG_SURVIVE) qn[p0++] = e & ID_MASK;
-          if (e & FLAG_SHADOW) rd.squeue[p1++] = e & ID_MASK;
-      }
-      __syncthreads();       // bases / wave_tot are reused by the next tile
+      __syncthreads();       // wcnt / bases are reused by the next tile
     }
     stat_add(rd.stats, ST_SKY, sky); stat_add(rd.stats, ST_LIMIT, limit); stat_add(rd.stats, ST_SCATTER, scat); stat_add(rd.stats, ST_SAMPLES, samples);
     if (depth > 0) stat_add(rd.stats, ST_DEPTH0 + (int)min(depth - 1, (uint32_t)RT_DEPTH_HIST_SIZE - 1), hist_miss);
@@ -273,17 +273,24 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
     const uint32_t n = rd.sqcount[depth];
     unsigned long long rays = 0, nodes = 0, prims = 0;
     int* stack = lds_stack + threadIdx.x;
-    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
-        uint32_t id = rd.squeue[j];
+    float4* next_l = rd.st[(depth & 1) ^ 1][2];
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < n; p += gridDim.x * BLOCK) {
+        float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
+        f3 wp = mk3(h0.x, h0.y, h0.z);
+        f3 nrm = mk3(h0.w, h1.x, h1.y);
+        col3 W = mkc(h1.z, h1.w, h2.x);
+        const uint32_t id = __float_as_uint(h2.y), dst = __float_as_uint(h2.z);
         RngKey key = path_key(rd, id);
-        f3 wp = mk3(rd.sh_wp[0][id], rd.sh_wp[1][id], rd.sh_wp[2][id]);
-        f3 nrm = mk3(rd.sh_n[0][id], rd.sh_n[1][id], rd.sh_n[2][id]);
-        col3 W = mkc(rd.sh_w[0][id], rd.sh_w[1][id], rd.sh_w[2][id]);
-        const rt_material* m = sc.materials + sc.obj_material[rd.hit_obj[id]];   // hit_obj still holds this bounce's hit
-        const bool phong = RT_HAS_MAT(C, RT_MAT_PHONG) && m->type == RT_MAT_PHONG;
+        const rt_material* m = nullptr;
+        bool phong = false;
+        f3 in = mk3(0, 0, 0);
+        if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
+            m = sc.materials + sc.obj_material[__float_as_uint(h2.w)];
+            phong = m->type == RT_MAT_PHONG;
+            if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+        }
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0);
-        f3 in = phong ? mk3(rd.sh_in[0][id], rd.sh_in[1][id], rd.sh_in[2][id]) : mk3(0, 0, 0);
         for (uint32_t s = 0; s < rd.light_samples; s++) {
             for (uint32_t li = 0; li < sc.n_lights; li++) {
                 const rt_light* l = sc.lights + li;
@@ -299,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
                     }
                 }
                 if (!phong) sum = sum + c;
-                else {                                                                    // PhongMaterial.cs:42-56
+                else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:42-56
                     ShadowRay s2 = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
                     col3 c2 = any_hit<C>(sc, s2.r, s2.kMin, s2.kMax, stack, BLOCK, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
@@ -316,7 +323,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
         col3 add;
         if (!phong) add = W * sum;
         else { spec_sum = spec_sum / S; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
-        rd.rad[0][id] += add.r; rd.rad[1][id] += add.g; rd.rad[2][id] += add.b;
+        float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
+        float4 t = *tgt;
+        if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
+        *tgt = t;
         nodes += cnt.nodes; prims += cnt.prims;
     }
     stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
@@ -330,8 +340,8 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum
         float* dst = accum + 3 * ((size_t)x + (size_t)yy * rd.width);
         float r = dst[0], g = dst[1], b = dst[2];
         for (uint32_t p = 0; p < n_passes; p++) {
-            size_t id = (size_t)p * rd.n_pixels + pix;
-            r += rd.rad[0][id]; g += rd.rad[1][id]; b += rd.rad[2][id];
+            float4 v = rd.out[(size_t)p * rd.n_pixels + pix];
+            r += v.x; g += v.y; b += v.z;
         }
         dst[0] = r; dst[1] = g; dst[2] = b;
     }

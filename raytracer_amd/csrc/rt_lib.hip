@@ -87,7 +87,7 @@ struct rt_scene {
 struct Slot {
     RenderDev rd{};
     hipStream_t stream = nullptr;
-    DevBuf f32_pool, u32_pool, counters;
+    DevBuf f32_pool, counters;
 };
 constexpr int MAX_SLOTS = 4;
 
@@ -432,30 +432,26 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
 
-    const int n_f32 = 6 + 3 + 3 + 2 + 12;     // ray, thr, rad, hit_k, hit_aux, shadow payload
-    const int n_u32 = 1 + 2 + 2 + 1;          // hit_obj, prev/first mat, 2 queues, shadow queue
     const uint32_t n_cnt = o->max_bounce_depth + 2;
+    const bool has_phong = (s->ks->mats >> RT_MAT_PHONG) & 1u, has_medium = (s->ks->prims >> RT_HIT_MEDIUM) & 1u;
     for (int si = 0; si < n_slots; si++) {
         Slot& sl = r->slots[si];
         if (si == 0) sl.stream = r->stream;
         else HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_acc[si], hipEventDisableTiming));
-        HIP_TRY(sl.f32_pool.alloc(P * n_f32 * sizeof(float)));
-        HIP_TRY(sl.u32_pool.alloc(P * n_u32 * sizeof(uint32_t)));
+        // float4 arrays: 2 x 4 state, 1 out, 3 (+1) shadow ; then hit (float2) and hit_aux (float)
+        const size_t n_f4 = 8 + 1 + 3 + (has_phong ? 1 : 0);
+        HIP_TRY(sl.f32_pool.alloc(P * (n_f4 * sizeof(float4) + sizeof(float2) + (has_medium ? sizeof(float) : 0))));
         HIP_TRY(sl.counters.alloc(2 * n_cnt * sizeof(uint32_t)));
         RenderDev& rd = sl.rd;
-        float* f = sl.f32_pool.as<float>(); uint32_t* u = sl.u32_pool.as<uint32_t>();
-        auto nf = [&]() { float* p = f; f += P; return p; };
-        auto nu = [&]() { uint32_t* p = u; u += P; return p; };
-        for (int i = 0; i < 6; i++) rd.ray[i] = nf();
-        for (int i = 0; i < 3; i++) rd.thr[i] = nf();
-        for (int i = 0; i < 3; i++) rd.rad[i] = nf();
-        rd.hit_k = nf(); rd.hit_aux = nf();
-        for (int i = 0; i < 3; i++) rd.sh_wp[i] = nf();
-        for (int i = 0; i < 3; i++) rd.sh_n[i] = nf();
-        for (int i = 0; i < 3; i++) rd.sh_w[i] = nf();
-        for (int i = 0; i < 3; i++) rd.sh_in[i] = nf();
-        rd.hit_obj = nu(); rd.prev_mat = nu(); rd.first_mat = nu(); rd.queue[0] = nu(); rd.queue[1] = nu(); rd.squeue = nu();
+        float4* f = sl.f32_pool.as<float4>();
+        auto nf = [&]() { float4* p = f; f += P; return p; };
+        for (int h = 0; h < 2; h++) for (int i = 0; i < 4; i++) rd.st[h][i] = nf();
+        rd.out = nf();
+        for (int i = 0; i < 3; i++) rd.sh[i] = nf();
+        rd.sh[3] = has_phong ? nf() : nullptr;
+        rd.hit = (float2*)f;
+        rd.hit_aux = has_medium ? (float*)(rd.hit + P) : nullptr;
         rd.qcount = sl.counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
         rd.stats = r->stats.as<unsigned long long>();
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
