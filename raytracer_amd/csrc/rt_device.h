@@ -116,6 +116,8 @@ struct SceneDev {
     const rt_light* lights;      uint32_t n_lights;
     rt_camera camera;
     rt_skybox skybox;
+    // small all-sphere scenes: a copy of the tree laid out for LDS (see LdsTree), null otherwise
+    const uint4* lds_image;      uint32_t lds_image_bytes;   // q0[n_nodes] q1[n_nodes] q2[n_nodes] children[n_nodes] (int2, padded to 16 B) spheres[n_objects]
 };
 
 struct Ray { f3 o, d; };
@@ -444,12 +446,56 @@ RT_FN void consider(Closest& best, float k, uint32_t obj, float aux) {
 
 RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(r.o.z) || is_nan(r.d.x) || is_nan(r.d.y) || is_nan(r.d.z); }
 
+// Where a traversal reads the tree from and where it keeps its stack.
+//   HbmTree: nodes and primitives come through the vector cache (L1 -> L2 -> Infinity Cache -> HBM); 32-bit stack column in LDS.
+//   LdsTree: the whole tree and the sphere table live in the workgroup's LDS (scenes of a few hundred objects): a divergent
+//            64-lane node fetch costs LDS cycles instead of 64 cache-line lookups in the texture path; 16-bit stack column.
+struct HbmTree {
+    int* stack; int stride;
+    RT_FN void node(const SceneDev& sc, int i, float4& q0, float4& q1, float4& q2, int2& ch) const {
+        const Node* np = sc.nodes + i;
+        q0 = np->q0; q1 = np->q1; q2 = np->q2; ch = *(const int2*)&np->q3;
+    }
+    RT_FN void push(int sp, int v) const { stack[sp * stride] = v; }
+    RT_FN int pop(int sp) const { return stack[sp * stride]; }
+    template <class C> RT_FN bool leaf_try(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax, float& k) const;
+    template <class C> RT_FN bool leaf_fast(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax) const;
+};
+template <class C> RT_FN bool HbmTree::leaf_try(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax, float& k) const {
+    uint32_t code = sc.obj_code[obj];
+    return try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax, k);
+}
+template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax) const {
+    uint32_t code = sc.obj_code[obj];
+    return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
+}
+struct LdsTree {
+    const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
+    unsigned short* stack; int stride;
+    RT_FN void node(const SceneDev&, int i, float4& a, float4& b, float4& c, int2& d) const { a = q0[i]; b = q1[i]; c = q2[i]; d = ch[i]; }
+    RT_FN void push(int sp, int v) const { stack[sp * stride] = (unsigned short)(v >= 0 ? v : (0x8000 | ~v)); }
+    RT_FN int pop(int sp) const { int e = stack[sp * stride]; return (e & 0x8000) ? ~(e & 0x7FFF) : e; }
+    template <class C> RT_FN bool leaf_try(const SceneDev&, uint32_t obj, Ray r, float kMin, float kMax, float& k) const { return try_sphere(sph[obj], r, kMin, kMax, k); }
+    template <class C> RT_FN bool leaf_fast(const SceneDev&, uint32_t obj, Ray r, float kMin, float kMax) const { float k; return try_sphere(sph[obj], r, kMin, kMax, k); }
+    // carve the LDS image (copied verbatim from SceneDev::lds_image) into its tables
+    RT_FN static LdsTree carve(const void* base, uint32_t n_nodes, uint32_t n_objects, uint32_t image_bytes, int tid, int block) {
+        LdsTree t;
+        const float4* f = (const float4*)base;
+        t.q0 = f; t.q1 = f + n_nodes; t.q2 = f + 2 * (size_t)n_nodes;
+        t.ch = (const int2*)(f + 3 * (size_t)n_nodes);
+        t.sph = f + 3 * (size_t)n_nodes + ((size_t)n_nodes + 1) / 2;
+        t.stack = (unsigned short*)((const char*)base + image_bytes) + tid; t.stride = block;
+        (void)n_objects;
+        return t;
+    }
+};
+
 // One traversal loop, one code site per kind of work: `cur` is either an inner node (>= 0: test both child boxes, go to the
 // nearer hit child, push the other) or a leaf (< 0: run the object's intersector).  A leaf's box is tested when its parent is
 // visited, with the best K known then — the reference's SingleObjectBvhNode test (SingleObjectBvhNode.cs:12-16); a K found later
 // only shrinks the range the intersector accepts, so the result is the same.
-template <class C>
-RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, int* stack, int stride, TravCount& cnt) {
+template <class C, class Tree>
+RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
     if (ray_has_nan(r)) return best;
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
@@ -463,8 +509,8 @@ RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, con
         int sp = 0, cur = 0;
         for (;;) {
             if (cur >= 0) {
-                const Node* np = sc.nodes + cur;
-                float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int2 ch = *(const int2*)&np->q3;
+                float4 q0, q1, q2; int2 ch;
+                tree.node(sc, cur, q0, q1, q2, ch);
                 cnt.nodes += 2;
                 float enA, exA, enB, exB;
                 slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
@@ -472,17 +518,17 @@ RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, con
                 const bool hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, best.k);
                 if (hA && hB) {                                    // nearer entry first (affects only the amount of work)
                     const bool bFirst = enB < enA;
-                    stack[sp * stride] = bFirst ? ch.x : ch.y; sp++;
+                    tree.push(sp, bFirst ? ch.x : ch.y); sp++;
                     cur = bFirst ? ch.y : ch.x;
                     continue;
                 }
                 if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
             } else {
-                uint32_t obj = (uint32_t)~cur, code = sc.obj_code[obj]; float k; cnt.prims++;
-                if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                uint32_t obj = (uint32_t)~cur; float k; cnt.prims++;
+                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
             }
             if (sp == 0) break;
-            sp--; cur = stack[sp * stride];
+            sp--; cur = tree.pop(sp);
         }
     }
     if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
@@ -501,8 +547,8 @@ RT_FN Closest closest_hit(const SceneDev& sc, Ray r, float kMin, float kMax, con
 
 // RenderJob.AnyIntersectionFast, Core/RenderJob.cs:575.  The reference scans every object's FastTryHit; culling by
 // conservative boxes returns the same boolean.
-template <class C>
-RT_FN bool any_hit(const SceneDev& sc, Ray r, float kMin, float kMax, int* stack, int stride, TravCount& cnt) {
+template <class C, class Tree>
+RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, TravCount& cnt) {
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
         uint32_t code = sc.obj_code[sc.unbounded[i]]; cnt.prims++;
         if (fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
@@ -519,8 +565,8 @@ RT_FN bool any_hit(const SceneDev& sc, Ray r, float kMin, float kMax, int* stack
     int sp = 0, cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const Node* np = sc.nodes + cur;
-            float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; int2 ch = *(const int2*)&np->q3;
+            float4 q0, q1, q2; int2 ch;
+            tree.node(sc, cur, q0, q1, q2, ch);
             cnt.nodes += 2;
             float enA, exA, enB, exB;
             slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
@@ -528,14 +574,14 @@ RT_FN bool any_hit(const SceneDev& sc, Ray r, float kMin, float kMax, int* stack
             const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
             const bool hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
             const bool hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
-            if (hA && hB) { stack[sp * stride] = ch.y; sp++; cur = ch.x; continue; }
+            if (hA && hB) { tree.push(sp, ch.y); sp++; cur = ch.x; continue; }
             if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
         } else {
-            uint32_t code = sc.obj_code[(uint32_t)~cur]; cnt.prims++;
-            if (fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
+            cnt.prims++;
+            if (tree.template leaf_fast<C>(sc, (uint32_t)~cur, r, kMin, kMax)) return true;
         }
         if (sp == 0) break;
-        sp--; cur = stack[sp * stride];
+        sp--; cur = tree.pop(sp);
     }
     return false;
 }

@@ -84,20 +84,39 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
     if (blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = rd.n_paths;
 }
 
-extern __shared__ int lds_stack[];   // [stack_depth][BLOCK]
+extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsTree: scene image, then ushort [stack_depth][block]
 
-template <class C>
-__global__ void __launch_bounds__(BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+// Traversal kernels come in two forms: TB = BLOCK reading the tree through the cache hierarchy, and (small all-sphere scenes)
+// TB = a larger workgroup that first copies the scene's LDS image and then never touches the vector cache for nodes or spheres.
+constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = 512;
+template <bool LDS, int TB>
+RT_FN auto make_tree(const SceneDev& sc) {
+    if constexpr (LDS) {
+        uint4* dst = (uint4*)lds_stack;
+        const uint32_t n16 = sc.lds_image_bytes / 16;
+        for (uint32_t i = threadIdx.x; i < n16; i += TB) dst[i] = sc.lds_image[i];
+        __syncthreads();
+        return LdsTree::carve(lds_stack, sc.n_nodes, sc.n_objects, sc.lds_image_bytes, (int)threadIdx.x, TB);
+    } else {
+        HbmTree t; t.stack = lds_stack + threadIdx.x; t.stride = TB;
+        return t;
+    }
+}
+
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
     unsigned long long rays = 0, nodes = 0, prims = 0;
-    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+    for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
         float4 a = g0[j], b = g1[j];
         Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
         RngKey key = make_key(0, 0, 0);
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, __float_as_uint(g3[j].x));     // only a medium draws random numbers
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        Closest c = closest_hit<C>(sc, r, rd.k_min, rd.k_max, key, depth, lds_stack + threadIdx.x, BLOCK, cnt);
+        Closest c = closest_hit<C>(sc, tree, r, rd.k_min, rd.k_max, key, depth, cnt);
         rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
         rays++; nodes += cnt.nodes; prims += cnt.prims;
@@ -268,13 +287,14 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
 }
 
 // Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
-template <class C>
-__global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
     unsigned long long rays = 0, nodes = 0, prims = 0;
-    int* stack = lds_stack + threadIdx.x;
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < n; p += gridDim.x * BLOCK) {
+    for (uint32_t p = blockIdx.x * TB + threadIdx.x; p < n; p += gridDim.x * TB) {
         float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
         f3 wp = mk3(h0.x, h0.y, h0.z);
         f3 nrm = mk3(h0.w, h1.x, h1.y);
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
                 ShadowRay sr = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
                 rays++;
                 col3 c = mkc(0, 0, 0);
-                if (!any_hit<C>(sc, sr.r, sr.kMin, sr.kMax, stack, BLOCK, cnt)) {
+                if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) {
                     if (!(sr.kMax > l->cutoff_radius)) {
                         float scale = attenuation(l, sr.kMax / l->attenuation_radius);
                         scale = maxf_net(scale, 0);
@@ -309,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(SceneDev sc, RenderDev rd, uin
                 else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:42-56
                     ShadowRay s2 = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
-                    col3 c2 = any_hit<C>(sc, s2.r, s2.kMin, s2.kMax, stack, BLOCK, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
+                    col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
                     f3 rl = reflect(s2.r.d, -nrm);
                     float sd = fabsf(dot(in, rl));
                     spec_sum = spec_sum + (c2 * powf(sd, powf(2.0f, m->f[9])));
@@ -359,13 +379,15 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t 
 }
 
 // Parity hooks: one thread per caller-supplied ray.
-template <class C>
-__global__ void __launch_bounds__(BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
+    constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
+    for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         RngKey key = make_key(seed, (uint32_t)i, 0);
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        Closest c = closest_hit<C>(sc, r, kMin, kMax, key, 0, lds_stack + threadIdx.x, BLOCK, cnt);
+        Closest c = closest_hit<C>(sc, tree, r, kMin, kMax, key, 0, cnt);
         rt_hit h = {};
         h.object = RT_NO_HIT; h.material = RT_NO_HIT;
         if (c.obj != RT_NO_HIT) {
@@ -380,12 +402,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(SceneDev sc, const rt_r
     }
 }
 
-template <class C>
-__global__ void __launch_bounds__(BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
+    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
+    for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
-        occluded[i] = any_hit<C>(sc, r, kMin[i], kMax[i], lds_stack + threadIdx.x, BLOCK, cnt) ? 1 : 0;
+        occluded[i] = any_hit<C>(sc, tree, r, kMin[i], kMax[i], cnt) ? 1 : 0;
     }
 }
 
@@ -409,9 +433,17 @@ struct KernelSet {
     void (*shadow)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
     void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+    // LdsTree forms (null when the variant has none)
+    void (*closest_lds)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
+    void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
+    void (*trace_any_lds)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
 };
-template <class C> constexpr KernelSet make_kernel_set(const char* name) {
-    return KernelSet{name, C::prims, C::mats, C::texs, C::lights, k_closest<C>, k_shade<C>, k_shadow<C>, k_trace_closest<C>, k_trace_any<C>};
+template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
+    KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
+                nullptr, nullptr, nullptr, nullptr};
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+    return k;
 }
 
 } // namespace rtd

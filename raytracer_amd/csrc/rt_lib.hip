@@ -65,7 +65,7 @@ inline bool finite3(const float* a) { return std::isfinite(a[0]) && std::isfinit
 namespace {
 // most specific first; the last entry covers everything
 const KernelSet g_kernel_sets[] = {
-    make_kernel_set<CfgSpheres>("spheres"), make_kernel_set<CfgMesh>("mesh"), make_kernel_set<CfgBoxes>("boxes"), make_kernel_set<CfgAll>("generic"),
+    make_kernel_set<CfgSpheres, true>("spheres"), make_kernel_set<CfgMesh, false>("mesh"), make_kernel_set<CfgBoxes, false>("boxes"), make_kernel_set<CfgAll, false>("generic"),
 };
 constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 } // namespace
@@ -75,6 +75,8 @@ struct rt_scene {
     const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
     SceneDev dev{};
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
+    bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    DevBuf lds_image;
     uint32_t n_objects = 0, n_lights = 0;
     int n_cu = 256;
     DevBuf nodes, obj_code, obj_material, unbounded, media, spheres, quads, triangles, inf_planes, axis[3], disks, boxes, capsules, cylinders,
@@ -183,6 +185,8 @@ static int check_prim(const rt_scene_desc* d, uint32_t type, uint32_t index, boo
     if (index > OBJ_INDEX_MASK) return fail(RT_ERR_TOO_LARGE, "more than 2^28 primitives of one type");
     return RT_OK;
 }
+
+static inline size_t lds_tree_bytes_for(size_t image_bytes, uint32_t stack_depth, int block) { return image_bytes + (size_t)stack_depth * block * sizeof(unsigned short); }
 
 int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (!d || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
@@ -329,6 +333,30 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2);
     if ((size_t)s->stack_depth * BLOCK * sizeof(int) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "BVH depth %u needs more LDS than one workgroup may use", bvh.max_depth);
     s->n_objects = d->n_objects; s->n_lights = d->n_lights;
+    // LDS image: every BVH leaf a sphere, and two workgroups' image + 16-bit stacks fit one CU's 160 KB
+    {
+        bool all_spheres = ks->closest_lds != nullptr && !nodes.empty();
+        for (uint32_t obj : box_obj) all_spheres = all_spheres && d->objects[obj].type == RT_HIT_SPHERE;
+        const size_t nn = nodes.size(), no = d->n_objects;
+        const size_t image_bytes = (3 * nn + (nn + 1) / 2 + no) * 16;
+        const size_t need = image_bytes + (size_t)s->stack_depth * LDS_BLOCK_CLOSEST * sizeof(unsigned short);
+        const char* no_lds = getenv("RT_HIP_NO_LDS_TREE");
+        if (all_spheres && nn < 32768 && no < 32768 && need <= 80 * 1024 && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+            std::vector<float4> img(image_bytes / 16, make_float4(0, 0, 0, 0));
+            for (size_t i = 0; i < nn; i++) { img[i] = nodes[i].q0; img[nn + i] = nodes[i].q1; img[2 * nn + i] = nodes[i].q2; }
+            int2* chp = (int2*)(img.data() + 3 * nn);
+            for (size_t i = 0; i < nn; i++) chp[i] = make_int2(nodes[i].q3.x, nodes[i].q3.y);
+            float4* sp = img.data() + 3 * nn + (nn + 1) / 2;
+            for (size_t i = 0; i < no; i++) if (d->objects[i].type == RT_HIT_SPHERE) sp[i] = spheres[d->objects[i].index];
+            if ((rc = upload(s->lds_image, img))) return rc;
+            sd.lds_image = s->lds_image.as<uint4>(); sd.lds_image_bytes = (uint32_t)image_bytes;
+            s->use_lds = true;
+            // more than 64 KB of dynamic LDS needs the per-function opt-in
+            const void* fns[4] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds};
+            for (int i = 0; i < 4; i++)
+                HIP_TRY(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree_bytes_for(image_bytes, s->stack_depth, i < 2 ? LDS_BLOCK_CLOSEST : LDS_BLOCK_SHADOW)));
+        }
+    }
     *out = s.release();
     return RT_OK;
 }
@@ -349,6 +377,13 @@ static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t block
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
 static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * sizeof(int); }
+static inline size_t lds_tree_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
+static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) {
+    uint64_t need = (work + block - 1) / block;
+    uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds_tree_bytes(s, block));
+    per_cu = std::min<uint64_t>(per_cu, 2048 / block);
+    return (uint32_t)std::max<uint64_t>(1, std::min(need, (uint64_t)s->n_cu * per_cu));
+}
 
 // -------------------------------------------------------------------------------------------------
 // Parity hooks
@@ -361,7 +396,8 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, f
     DevBuf dr, dh;
     HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dh.alloc(n * sizeof(rt_hit)));
     HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
+    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
+    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
@@ -378,7 +414,8 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d0.p, k_min, n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d1.p, k_max, n * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
+    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
+    else hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(occluded, dout.p, n, hipMemcpyDeviceToHost));
@@ -494,9 +531,13 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     const size_t lds = stack_bytes(s);
     { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= r->opts.max_bounce_depth; depth++) {
-        { Timed t(r, RT_K_CLOSEST, st); hipLaunchKernelGGL(ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+        { Timed t(r, RT_K_CLOSEST, st);
+          if (s->use_lds) hipLaunchKernelGGL(ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
+          else hipLaunchKernelGGL(ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(ks->shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
-        if (s->n_lights) { Timed t(r, RT_K_SHADOW, st); hipLaunchKernelGGL(ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+        if (s->n_lights) { Timed t(r, RT_K_SHADOW, st);
+          if (s->use_lds) hipLaunchKernelGGL(ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          else hipLaunchKernelGGL(ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on
     if (r->batches_enqueued > 0 && r->n_slots > 1) HIP_TRY(hipStreamWaitEvent(st, r->ev_acc[(si + r->n_slots - 1) % r->n_slots], 0));
