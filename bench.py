@@ -140,6 +140,7 @@ def main():
         "mrays_per_s": {"closest": rays_all / dt / 1e6, "shadow": shadow_all / dt / 1e6, "total": (rays_all + shadow_all) / dt / 1e6},
         "scene_upload_and_bvh_s": scene_upload_s,
         "ray_depth_counts": job.RenderStats.RayDepthCounts[:MAX_DEPTH + 1],
+        "scene_info": dev_scene.Info(),
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:

@@ -321,6 +321,17 @@ int rt_device_count(int* n);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 
+/* What the library built for a scene: the shape of its BVH (the reference exposes RenderJob.BvhTree, RenderJob.cs:660) and
+ * which kernel variant / tree placement the trace kernels will use. */
+typedef struct rt_scene_info {
+    uint32_t n_objects, n_unbounded;  /* objects outside the BVH because their BoundingVolume is not finite */
+    uint32_t n_nodes, bvh_depth;      /* inner nodes (64 B each) and deepest inner level */
+    uint32_t tree_in_lds;             /* 1: the tree and sphere table are copied into each workgroup's LDS */
+    uint32_t lds_image_bytes;
+    char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
+} rt_scene_info;
+int rt_scene_get_info(rt_scene* scene, rt_scene_info* out);
+
 /* RenderJob ctor (RenderJob.cs:34-62): allocates the colour-sum and sample-count state. */
 int rt_render_create(rt_scene* scene, const rt_render_opts* opts, rt_render** out);
 int rt_render_destroy(rt_render* render);

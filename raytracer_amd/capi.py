@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")     # RT_HIP_LIB: A/B a differently built library
 
 RT_ABI_VERSION = 1
 RT_NO_HIT = 0xFFFFFFFF
@@ -133,6 +133,11 @@ class KernelProfile(C.Structure):
         return {n: {"launches": int(self.launches[i]), "total_ms": float(self.total_ms[i])} for i, n in enumerate(RT_K_NAMES)}
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("n_objects", C.c_uint32), ("n_unbounded", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
+                ("tree_in_lds", C.c_uint32), ("lds_image_bytes", C.c_uint32), ("variant", C.c_char * 16)]
+
+
 class Ray(C.Structure):
     _fields_ = [("origin", F3), ("direction", F3)]
 
@@ -149,6 +154,7 @@ SYMBOLS = {
     "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (C.c_int, [C.c_void_p]),
+    "rt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "rt_render_create": (C.c_int, [C.c_void_p, C.POINTER(RenderOpts), C.POINTER(C.c_void_p)]),
     "rt_render_destroy": (C.c_int, [C.c_void_p]),
     "rt_render_passes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
@@ -180,7 +186,12 @@ def load():
             raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); there is no CPU fallback")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if os.environ.get("RT_HIP_LIB"):
+                    continue          # an older build under A/B test may lack newer entry points
+                raise
             fn.restype = res
             fn.argtypes = args
         if lib.rt_version() != RT_ABI_VERSION:

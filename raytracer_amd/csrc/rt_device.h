@@ -90,6 +90,7 @@ RT_FN f3 on_unit_sphere(float a, float b, float c) {                            
 // is the reference's SingleObjectBvhNode box test (Core/Acceleration/SingleObjectBvhNode.cs:12-16).
 struct Node { float4 q0, q1, q2; int4 q3; };
 constexpr int CHILD_EMPTY = (int)0x80000000;
+constexpr int TRAV_DONE = CHILD_EMPTY;      // traversal cursor: nothing left (never a valid leaf code)
 
 constexpr uint32_t OBJ_TYPE_SHIFT = 28;
 constexpr uint32_t OBJ_INDEX_MASK = (1u << OBJ_TYPE_SHIFT) - 1;
@@ -490,10 +491,58 @@ struct LdsTree {
     }
 };
 
-// One traversal loop, one code site per kind of work: `cur` is either an inner node (>= 0: test both child boxes, go to the
-// nearer hit child, push the other) or a leaf (< 0: run the object's intersector).  A leaf's box is tested when its parent is
+// Traversal: `cur` is an inner node (>= 0: test both child boxes, go to the nearer hit child, push the other) or a leaf
+// (< 0: run the object's intersector).  While-while with one postponed leaf: a lane that reaches a leaf parks it and keeps
+// descending until it meets a second one, so the 64 lanes of a wave do box tests together and then intersect together
+// instead of paying for both kinds of work on every iteration (closest hit does not depend on the order of the tests).  A leaf's box is tested when its parent is
 // visited, with the best K known then — the reference's SingleObjectBvhNode test (SingleObjectBvhNode.cs:12-16); a K found later
 // only shrinks the range the intersector accepts, so the result is the same.
+// One inner-node step: test both child boxes against [kMin, kMax] (kMax = the best K so far for closest hit), continue with
+// the nearer hit child, push the other, pop when neither is hit; a leaf met while no leaf is parked is parked in `pend` and
+// the descent goes on.  ANY = any-hit rule: closed box interval, no near/far ordering.
+template <bool ANY, class Tree>
+RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Ray& r, f3 invD, float kMin, float kMax, int& cur, int& pend, int& sp) {
+    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
+    float4 q0, q1, q2; int2 ch;
+    tree.node(sc, cur, q0, q1, q2, ch);
+    float enA, exA, enB, exB;
+    slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+    bool hA, hB;
+    if (ANY) {     // a hit exactly on a box face must never be culled: exit >= entry
+        const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
+        hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
+        hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
+    } else {
+        hA = (ch.x != CHILD_EMPTY) && slab_hit(enA, exA, kMax);
+        hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, kMax);
+    }
+    int next = ch.x; bool pop = false;
+    if (hA && hB) {
+        const bool bFirst = !ANY && (enB < enA);               // nearer entry first (affects only the amount of work)
+        tree.push(sp, bFirst ? ch.x : ch.y); sp++;
+        next = bFirst ? ch.y : ch.x;
+    } else if (hB) next = ch.y;
+    else if (!hA) pop = true;
+    if (!pop && next < 0 && pend == TRAV_DONE) { pend = next; pop = true; }   // park one leaf, keep descending
+    if (pop) {
+        if (sp) { sp--; next = tree.pop(sp); } else next = TRAV_DONE;
+        if (next < 0 && next != TRAV_DONE && pend == TRAV_DONE) {          // the popped entry is a leaf and the parking slot is free
+            pend = next;
+            if (sp) { sp--; next = tree.pop(sp); } else next = TRAV_DONE;
+        }
+    }
+    cur = next;                                                            // invariant on return: a leaf in `cur` implies a leaf in `pend`
+}
+// After the parked leaf has been tested: a second leaf waiting in `cur` takes its place and the descent resumes from the stack.
+template <class Tree>
+RT_FN void leaf_advance(const Tree& tree, int& cur, int& pend, int& sp) {
+    pend = TRAV_DONE;
+    if (cur < 0 && cur != TRAV_DONE) {
+        pend = cur;
+        if (sp) { sp--; cur = tree.pop(sp); } else cur = TRAV_DONE;
+    }
+}
+
 template <class C, class Tree>
 RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
@@ -505,30 +554,15 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
     }
     if (sc.n_nodes) {
         const f3 invD = splat(1.0f) / r.d;
-        RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
-        int sp = 0, cur = 0;
+        int sp = 0, cur = 0, pend = TRAV_DONE;
         for (;;) {
-            if (cur >= 0) {
-                float4 q0, q1, q2; int2 ch;
-                tree.node(sc, cur, q0, q1, q2, ch);
-                cnt.nodes += 2;
-                float enA, exA, enB, exB;
-                slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
-                const bool hA = (ch.x != CHILD_EMPTY) && slab_hit(enA, exA, best.k);
-                const bool hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, best.k);
-                if (hA && hB) {                                    // nearer entry first (affects only the amount of work)
-                    const bool bFirst = enB < enA;
-                    tree.push(sp, bFirst ? ch.x : ch.y); sp++;
-                    cur = bFirst ? ch.y : ch.x;
-                    continue;
-                }
-                if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
-            } else {
-                uint32_t obj = (uint32_t)~cur; float k; cnt.prims++;
+            while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }   // every lane does box tests here
+            if (pend != TRAV_DONE) {                               // leaves: most lanes arrive here with one parked
+                uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
                 if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
             }
-            if (sp == 0) break;
-            sp--; cur = tree.pop(sp);
+            if (cur == TRAV_DONE) break;
+            leaf_advance(tree, cur, pend, sp);
         }
     }
     if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
@@ -561,27 +595,15 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
     }
     if (!sc.n_nodes) return false;
     const f3 invD = splat(1.0f) / r.d;
-    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
-    int sp = 0, cur = 0;
+    int sp = 0, cur = 0, pend = TRAV_DONE;
     for (;;) {
-        if (cur >= 0) {
-            float4 q0, q1, q2; int2 ch;
-            tree.node(sc, cur, q0, q1, q2, ch);
-            cnt.nodes += 2;
-            float enA, exA, enB, exB;
-            slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
-            // any-hit boxes use a closed interval (exit >= entry) so a hit exactly on a box face is never culled
-            const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
-            const bool hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
-            const bool hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
-            if (hA && hB) { tree.push(sp, ch.y); sp++; cur = ch.x; continue; }
-            if (hA || hB) { cur = hA ? ch.x : ch.y; continue; }
-        } else {
+        while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
+        if (pend != TRAV_DONE) {
             cnt.prims++;
-            if (tree.template leaf_fast<C>(sc, (uint32_t)~cur, r, kMin, kMax)) return true;
+            if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) return true;
         }
-        if (sp == 0) break;
-        sp--; cur = tree.pop(sp);
+        if (cur == TRAV_DONE) break;
+        leaf_advance(tree, cur, pend, sp);
     }
     return false;
 }

@@ -75,6 +75,7 @@ struct rt_scene {
     const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
     SceneDev dev{};
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
+    uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
     DevBuf lds_image;
     uint32_t n_objects = 0, n_lights = 0;
@@ -330,7 +331,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     sd.media_rec = s->media_rec.as<rt_medium>(); sd.materials = s->materials.as<rt_material>(); sd.textures = s->textures.as<rt_texture>();
     sd.lights = s->lights.as<rt_light>(); sd.n_lights = d->n_lights;
     sd.camera = d->camera; sd.skybox = d->skybox;
-    s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2);
+    s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2); s->bvh_depth = bvh.max_depth;
     if ((size_t)s->stack_depth * BLOCK * sizeof(int) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "BVH depth %u needs more LDS than one workgroup may use", bvh.max_depth);
     s->n_objects = d->n_objects; s->n_lights = d->n_lights;
     // LDS image: every BVH leaf a sphere, and two workgroups' image + 16-bit stacks fit one CU's 160 KB
@@ -358,6 +359,15 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         }
     }
     *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_get_info: null argument");
+    memset(out, 0, sizeof(*out));
+    out->n_objects = s->n_objects; out->n_unbounded = s->dev.n_unbounded; out->n_nodes = s->dev.n_nodes; out->bvh_depth = s->bvh_depth;
+    out->tree_in_lds = s->use_lds ? 1u : 0u; out->lds_image_bytes = s->dev.lds_image_bytes;
+    strncpy(out->variant, s->ks->name, sizeof(out->variant) - 1);
     return RT_OK;
 }
 
@@ -391,7 +401,7 @@ static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) {
 int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits) {
     if (!s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_trace_closest: null argument");
     if (!n) return RT_OK;
-    if (n > (1ull << 32) - 1) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest: at most 2^32-1 rays per call");
+    if (n > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest: at most 2^31 rays per call");
     DeviceGuard guard(s->device);
     DevBuf dr, dh;
     HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dh.alloc(n * sizeof(rt_hit)));
@@ -407,7 +417,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, f
 int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const float* k_max, uint64_t n, uint8_t* occluded) {
     if (!s || (n && (!rays || !k_min || !k_max || !occluded))) return fail(RT_ERR_INVALID_ARG, "rt_trace_any: null argument");
     if (!n) return RT_OK;
-    if (n > (1ull << 32) - 1) return fail(RT_ERR_TOO_LARGE, "rt_trace_any: at most 2^32-1 rays per call");
+    if (n > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "rt_trace_any: at most 2^31 rays per call");
     DeviceGuard guard(s->device);
     DevBuf dr, d0, d1, dout;
     HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(d0.alloc(n * sizeof(float))); HIP_TRY(d1.alloc(n * sizeof(float))); HIP_TRY(dout.alloc(n));

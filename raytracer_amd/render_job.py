@@ -49,6 +49,13 @@ class DeviceScene:
         self.handle = C.c_void_p()
         capi.check(self._lib.rt_scene_create(C.byref(self.flat.desc), device, C.byref(self.handle)))
 
+    def Info(self) -> dict:
+        """Shape of the device BVH and the kernel variant chosen (rt_scene_get_info)."""
+        si = capi.SceneInfo()
+        capi.check(self._lib.rt_scene_get_info(self.handle, C.byref(si)))
+        return {"n_objects": si.n_objects, "n_unbounded": si.n_unbounded, "n_nodes": si.n_nodes, "bvh_depth": si.bvh_depth,
+                "tree_in_lds": bool(si.tree_in_lds), "lds_image_bytes": si.lds_image_bytes, "variant": si.variant.decode()}
+
     def TraceClosest(self, origins, directions, kMin=0.001, kMax=np.inf, seed=0):
         """RenderJob.TryFindClosestHit (RenderJob.cs:581-617) on a batch of rays -> structured array of rt_hit."""
         rays = _pack_rays(origins, directions)

@@ -17,7 +17,7 @@ STRUCTS = {
     "rt_axis_plane": capi.AxisPlane, "rt_disk": capi.Disk, "rt_box": capi.Box, "rt_capsule": capi.Capsule, "rt_cylinder": capi.Cylinder,
     "rt_medium": capi.Medium, "rt_object": capi.Object, "rt_texture": capi.Texture, "rt_material": capi.Material, "rt_light": capi.Light,
     "rt_skybox": capi.SkyBox, "rt_camera": capi.Camera, "rt_scene_desc": capi.SceneDesc, "rt_render_opts": capi.RenderOpts,
-    "rt_stats": capi.Stats, "rt_ray": capi.Ray, "rt_hit": capi.Hit,
+    "rt_stats": capi.Stats, "rt_ray": capi.Ray, "rt_hit": capi.Hit, "rt_scene_info": capi.SceneInfo, "rt_kernel_profile": capi.KernelProfile,
 }
 
 
