@@ -79,10 +79,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only trace path (no CPU fallback)")
+    if os.environ.get("RT_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") over xGMI is the real path; RT_BENCH_BACKEND=gloo + RT_BENCH_ONE_GPU=1 rehearse the N > 1 code on a 1-GPU box
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import raytracer_amd as rt
     from raytracer_amd.core import RenderOptions

