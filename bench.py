@@ -5,8 +5,9 @@
 
 Workload (config.workload): BASELINE.json configs[1], "Night Spheres" 1920x1080 — BuiltinScenes.Testing with a
 seeded generator: 479 spheres + ground plane + 1 DiffuseSphereLight, depth 10, 2 light samples.
-One step = PASSES_PER_STEP (32) passes over the whole 1080p frame = 66.4 M samples traced, shaded and accumulated
-(four wavefront batches of 8 passes); the default 8 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
+One step = PASSES_PER_STEP (128) passes over the whole 1080p frame = 265 M samples traced, shaded and accumulated
+(two wavefront batches of 64 passes, sized for 288 GB of HBM: the deep bounces of a small batch are latency-bound launches);
+the default 2 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
 timed region.  With N > 1 every rank renders its own passes (rank, rank+N, ...) — weak scaling — and the timed
 region ends with the one sum-reduce of the colour buffers to rank 0 (RCCL) and the RGB24 resolve.
 
@@ -23,8 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PASSES_PER_STEP = 32      # passes per step (one blocking rt_render_passes call)
-PASSES_PER_BATCH = 8      # passes per wavefront batch (16.6 M paths); the library keeps several batches in flight
+PASSES_PER_STEP = 128     # passes per step (one blocking rt_render_passes call)
+PASSES_PER_BATCH = 64     # passes per wavefront batch (133 M paths, 27 GB of path state); the library keeps two batches in flight
 WIDTH, HEIGHT = 1920, 1080
 MAX_DEPTH, LIGHT_SAMPLES = 10, 2
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
@@ -59,13 +60,17 @@ def stats_dict(job):
 
 
 def main():
+    global PASSES_PER_STEP, PASSES_PER_BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--passes-per-step", type=int, default=PASSES_PER_STEP)
+    ap.add_argument("--passes-per-batch", type=int, default=PASSES_PER_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    PASSES_PER_STEP, PASSES_PER_BATCH = args.passes_per_step, args.passes_per_batch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

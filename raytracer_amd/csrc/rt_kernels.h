@@ -169,9 +169,16 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
       }
       __syncthreads();
       uint32_t row_s = bases[0], row_l = bases[1];
+      // the next position's state is in flight while this one is shaded (the loads are the kernel's critical resource)
+      float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0; float2 nh = make_float2(0, 0);
+      { const uint32_t j0 = tile + threadIdx.x;
+        if (j0 < n) { n0 = rd.st[cur][0][j0]; n1 = rd.st[cur][1][j0]; n2 = rd.st[cur][2][j0]; n3 = rd.st[cur][3][j0]; nh = rd.hit[j0]; } }
 #pragma unroll 1
       for (int item = 0; item < SHADE_ITEMS; item++) {
         const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
+        const float4 a0 = n0, a1 = n1, a2 = n2, a3 = n3; const float2 hk = nh;
+        { const uint32_t jn = j + BLOCK;
+          if (item + 1 < SHADE_ITEMS && jn < n) { n0 = rd.st[cur][0][jn]; n1 = rd.st[cur][1][jn]; n2 = rd.st[cur][2][jn]; n3 = rd.st[cur][3][jn]; nh = rd.hit[jn]; } }
         const bool survive = (m_surv >> item) & 1u, shadow = (m_shad >> item) & 1u;
         // this path's output positions: rows before, waves before in the row, lanes before in the wave
         uint32_t p0 = row_s, p1 = row_l;
@@ -183,12 +190,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
         p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
         p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
         if (j < n) {
-            float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j], a3 = rd.st[cur][3][j];
             Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
             col3 T = mkc(a1.z, a1.w, a2.x);
             col3 L = mkc(a2.y, a2.z, a2.w);
             const uint32_t id = __float_as_uint(a3.x);
-            float2 hk = rd.hit[j];
             Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
             if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) c.aux = rd.hit_aux[j];
             if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450

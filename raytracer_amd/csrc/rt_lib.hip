@@ -452,8 +452,9 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     DeviceGuard guard(s->device);
     auto r = std::make_unique<rt_render>();
     r->scene = s; r->opts = *o;
-    // paths per batch: enough to keep 256 CUs busy at deep bounces, bounded so the state stays a few GiB
-    const uint64_t target_paths = 16ull << 20;
+    // paths per batch: the alive paths fall to ~1 % by bounce 10, and a launch needs >> 0.5 M rays to fill 256 CUs, so batches are
+    // big (128 M paths = 26 GB of state per slot): sized for 288 GB of HBM, not for a cache
+    const uint64_t target_paths = 128ull << 20;
     uint32_t ppb = o->passes_per_batch ? o->passes_per_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
     if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
     r->passes_per_batch = ppb;

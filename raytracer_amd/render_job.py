@@ -106,7 +106,8 @@ def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0) -> capi.Ren
     ro.max_bounce_depth, ro.light_sample_count_hint = o.MaxBounceDepth, o.LightSampleCountHint
     ro.debug_visualisation = o.DebugVisualisation
     ro.seed = o.Seed
-    ro.passes_per_batch = o.PassesPerBatch
+    # 0 = library default (up to 64 passes / 128 M paths per batch); never allocate state for more passes than the job renders
+    ro.passes_per_batch = o.PassesPerBatch or min(64, max(1, (128 << 20) // max(1, o.RenderWidth * o.RenderHeight)), max(1, o.Passes))
     ro.device = device
     ro.stream = stream or None
     ro.accum_device = accum_device or None
