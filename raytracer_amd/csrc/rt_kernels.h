@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(Scene
                 col3 c = mkc(0, 0, 0);
                 if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) {
                     if (!(sr.kMax > l->cutoff_radius)) {
-                        float scale = attenuation(l, sr.kMax / l->attenuation_radius);
+                        float scale = attenuation(l, sr.kMax * rcp_fast(l->attenuation_radius));
                         scale = maxf_net(scale, 0);
                         c = mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
                     }
@@ -346,11 +346,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(Scene
                 }
             }
         }
-        float S = (float)rd.light_samples;
-        sum = sum / S;
+        float S = (float)rd.light_samples, invS = rcp_fast(S);
+        sum = sum * invS;
         col3 add;
         if (!phong) add = W * sum;
-        else { spec_sum = spec_sum / S; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
+        else { spec_sum = spec_sum * invS; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
         float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
         float4 t = *tgt;
         if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
