@@ -56,7 +56,8 @@ def algorithmic_work(stats_delta, which):
 def stats_dict(job):
     s = job.UpdateStats()
     return {"ray_count": s.RayCount, "shadow_rays": s.ShadowRays, "node_visits": s.NodeVisits, "prim_tests": s.PrimTests,
-            "shadow_node_visits": s.ShadowNodeVisits, "shadow_prim_tests": s.ShadowPrimTests, "pixels": s.PixelsRendered}
+            "shadow_node_visits": s.ShadowNodeVisits, "shadow_prim_tests": s.ShadowPrimTests, "pixels": s.PixelsRendered,
+            "scatter": s.MaterialScatterCount, "limit": s.BounceLimitExceeded}
 
 
 def main():
@@ -156,33 +157,50 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        # a separate, event-timed leg (same workload, 1 more step, batches one at a time): per-kernel durations on the library's own stream
+        # a separate, event-timed leg (same workload, 1 more step, batches one at a time so that kernels do not overlap):
+        # per-kernel durations from HIP events on the library's own stream (rt_render_set_profiling)
         job.SetProfiling(True)
         p0 = stats_dict(job)
-        for i in range(1):
-            step(total_steps + i)
+        step(total_steps)
         prof = job.KernelProfile()
         job.SetProfiling(False)
         p1 = stats_dict(job)
         pd = {k: p1[k] - p0[k] for k in p0}
-        dominant = max(("closest", "shadow"), key=lambda k: prof[k]["total_ms"])
-        flops, byts = algorithmic_work(pd, dominant)
-        sec = prof[dominant]["total_ms"] / 1e3
-        launches = prof[dominant]["launches"]
-        achieved = flops / sec / 1e12
-        out["roofline"] = {"kernel": "k_" + dominant, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
-                           "launches": launches, "avg_launch_ms": prof[dominant]["total_ms"] / max(launches, 1),
-                           "algorithmic_flops_per_launch": flops / max(launches, 1), "algorithmic_bytes_per_launch": byts / max(launches, 1),
-                           "hbm": {"achieved": byts / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / sec / 1e9 / HBM_PEAK_GBS},
-                           "note": "scene (31 KB of nodes + 8 KB of spheres) is cache-resident: the bound is FP32 VALU issue + latency, not HBM or MFMA; "
-                                   "peak counts an FMA as 2 flops, the kernels run with -ffp-contract=off (bit-parity), i.e. at most half of it"}
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")       # PMC FETCH_SIZE/WRITE_SIZE of this workload (separate rocprofv3 passes)
+        if os.path.exists(tpath) and PASSES_PER_BATCH == 64:
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tpath))["kernels"].items()}
+        dominant = max(("closest", "shadow", "shade"), key=lambda k: prof[k]["total_ms"])
+
+        def valu_roofline(which):
+            flops, byts = algorithmic_work(pd, which)
+            sec, launches = prof[which]["total_ms"] / 1e3, max(prof[which]["launches"], 1)
+            tr = traffic.get("k_" + which)
+            return {"kernel": "k_" + which, "bound": "valu", "achieved": flops / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / sec / 1e12 / VALU_PEAK_TFLOPS, "traffic": tr, "launches": launches, "avg_launch_ms": prof[which]["total_ms"] / launches,
+                    "algorithmic_flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": byts / launches,
+                    "hbm_gbs_from_traffic": (tr * launches / sec / 1e9) if tr else None,
+                    "note": "FP32 vector peak (= the f32 MFMA peak; nothing here is a dense contraction). It counts an FMA as 2 flops and the kernels are built "
+                            "-ffp-contract=off for bit-parity, so half of it is their ceiling. algorithmic_bytes are BVH node / primitive bytes (SURVEY 8d): "
+                            "this scene's tree lives in LDS, so they never reach HBM; `traffic` is what does (path state), from PMC counters."}
+
+        def shade_roofline():
+            # k_shade moves path state: 72 B read per alive path, 64 B written per survivor, 48 B per shadow request, 16 B per finished path
+            alive, scat, fin = pd["ray_count"], pd["scatter"], pd["pixels"]
+            byts = 72 * alive + 64 * (scat - pd["limit"]) + 48 * (pd["shadow_rays"] // LIGHT_SAMPLES) + 16 * fin
+            sec, launches = prof["shade"]["total_ms"] / 1e3, max(prof["shade"]["launches"], 1)
+            return {"kernel": "k_shade", "bound": "hbm", "achieved": byts / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / sec / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic.get("k_shade"), "launches": launches, "avg_launch_ms": prof["shade"]["total_ms"] / launches,
+                    "algorithmic_bytes_per_launch": byts / launches}
+
+        out["roofline"] = shade_roofline() if dominant == "shade" else valu_roofline(dominant)
+        out["roofline_others"] = [valu_roofline(k) for k in ("closest", "shadow") if k != dominant] + ([shade_roofline()] if dominant != "shade" else [])
         out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
         threads = min(16, os.cpu_count() or 1)
-        cw, ch, cp = 960, 540, 2
+        cw, ch, cp = 1920, 1080, 10          # ~20 M samples: 10 s of work for 16 host threads
         copt = RenderOptions(RenderWidth=cw, RenderHeight=ch, Passes=cp, MaxBounceDepth=MAX_DEPTH, LightSampleCountHint=LIGHT_SAMPLES)
         osc = ob.OracleScene(dev_scene.flat)
         t0 = time.perf_counter()
