@@ -181,7 +181,6 @@ internal sealed unsafe class HipRenderBackend
 	public void Render(RenderJob job, CancellationToken ct)
 	{
 		Scene scene = job.Scene; RenderOptions o = job.RenderOptions;
-		if (o.DebugVisualisation != Debugging.GraphicsDebugVisualisation.None) throw new NotSupportedException("debug visualisations are not implemented by the HIP backend");
 		DeviceSceneBuilder b = new();
 		foreach (SceneObject so in scene.SceneObjects) b.IdOf(so.Hittable);   // each Hittable.Flatten calls b.AddObject(...)
 		foreach (Light l in scene.Lights) b.IdOf(l);
@@ -213,7 +212,7 @@ internal sealed unsafe class HipRenderBackend
 			RtHip.RenderOpts ro = new()
 			{
 					StructSize = (uint)sizeof(RtHip.RenderOpts), Width = (uint)o.RenderWidth, Height = (uint)o.RenderHeight, KMin = o.KMin, KMax = o.KMax,
-					MaxBounceDepth = (uint)o.MaxBounceDepth, LightSampleCountHint = (uint)o.LightSampleCountHint, DebugVisualisation = 0,
+					MaxBounceDepth = (uint)o.MaxBounceDepth, LightSampleCountHint = (uint)o.LightSampleCountHint, DebugVisualisation = (uint)o.DebugVisualisation,   // rt_debug_vis has the enum's values
 					Seed = (ulong)Random.Shared.NextInt64(), PassesPerBatch = 0, Device = -1, Stream = IntPtr.Zero, AccumDevice = null
 			};
 			RtHip.Check(RtHip.rt_render_create(hScene, &ro, out hRender));

@@ -253,9 +253,25 @@ typedef struct rt_scene_desc {
 
 /* RenderOptions (Ararem.RayTracer.Core/RenderOptions.cs:11-19) minus what stays host-side
  * (ConcurrencyLevel, Passes/InfinitePasses: the caller loops over rt_render_passes). */
-typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61; only NONE is rendered today */
-    RT_VIS_NONE = 0
+typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61, same values; RenderJob.cs:148-309 says what each one shows */
+    RT_VIS_NONE = 0,
+    RT_VIS_NORMALS = 1,              /* (N + 1) / 2 of the first hit                                            :156-162 */
+    RT_VIS_FACE_DIRECTION = 2,       /* OutsideFace ? green : red                                               :163-168 */
+    RT_VIS_DISTANCE_CLOSE = 3,       /* Pow(E, -(0.01 z^2)), z = K - KMin                                       :181-188 */
+    RT_VIS_DISTANCE_MID = 4,         /* Pow(E, -(0.0001 z^2))                                                   :189-196 */
+    RT_VIS_DISTANCE_FAR = 5,         /* Pow(E, -(0.000001 z^2))                                                 :197-204 */
+    RT_VIS_UV_COORDS = 6,            /* (u, v, 1)                                                               :229-233 */
+    RT_VIS_PIXEL_COORD_TEXTURE = 7,  /* per-material colour, checker from Sin(x/2) Sin(y/2) < 0                 :206-210 */
+    RT_VIS_SCATTER_DIRECTION = 8,    /* (Scatter(hit).Direction + 1) / 2                                        :221-228 */
+    RT_VIS_LOCAL_COORD_TEXTURE = 9,  /* checker from Sin(40 lx) Sin(40 ly) Sin(40 lz) < 0 on HitRecord.LocalPoint :216-220 */
+    RT_VIS_WORLD_COORD_TEXTURE = 10, /* the same on WorldPoint                                                  :211-215 */
+    RT_VIS_ESTIMATED_LIGHT = 11,     /* sum of Light.CalculateLight over lights and samples / samples           :234-250 */
+    RT_VIS_UNDEFINED_TEST = 12,      /* the reference throws ArgumentOutOfRangeException (:307-308): RT_ERR_INVALID_ARG */
+    RT_VIS_BOUNCE_DEPTH = 13         /* bounce loop without colours; Lerp(White, Blue*0.02, 1 - Pow(E, -(d^2 Sqrt(MaxBounceDepth)))), purple on a primary miss :251-306 */
 } rt_debug_vis;
+/* The per-material colour of the three "debug textures" is UniqueColourFromMaterialHash (RenderJob.cs:317-328): bytes [o..o+2] of
+ * Material.GetHashCode(), o = 1 for the alternate checker cell.  GetHashCode of a reference type is a per-process identity hash, so it
+ * cannot be reproduced; this library uses hash = (material id + 1) * 2654435761 (mod 2^32) in its place. */
 
 typedef struct rt_render_opts {
     uint32_t struct_size;            /* sizeof(rt_render_opts) */

@@ -1046,7 +1046,18 @@ static Colour CalculateRayColourLooped(const RenderCtx& rc, const Ray& initialRa
     return finalColour;
 }
 
-// RenderJob.RenderPixelWithVisualisations (None branch), Core/RenderJob.cs:135-151
+// RenderJob.UniqueColourFromMaterialHash, Core/RenderJob.cs:317-328.  Material.GetHashCode() is an identity hash that differs from
+// process to process; (material id + 1) * 2654435761 stands in for it (deviation D5, the same on the device).
+static Colour UniqueColourFromMaterialHash(uint32_t material, bool alternate) {
+    uint32_t hash = (material + 1u) * 2654435761u;
+    int o = alternate ? 1 : 0;
+    float rh = (float)((hash >> (8 * (o + 0))) & 0xFFu) / 255.0f;
+    float gh = (float)((hash >> (8 * (o + 1))) & 0xFFu) / 255.0f;
+    float bh = (float)((hash >> (8 * (o + 2))) & 0xFFu) / 255.0f;
+    return {rh, gh, bh};
+}
+
+// RenderJob.RenderPixelWithVisualisations, Core/RenderJob.cs:135-310
 static Colour RenderPixel(const RenderCtx& rc, uint32_t x, uint32_t y, uint64_t pass, Stats& st, std::vector<HitRecord>& scratch) {
     SampleKey key; key.seed = rc.opts.seed; key.pixel = x + y * rc.opts.width; key.pass = pass; key.depth = 0;
     SampleKey::F4 r = key.draw(SLOT_CAMERA, 0);
@@ -1055,7 +1066,54 @@ static Colour RenderPixel(const RenderCtx& rc, uint32_t x, uint32_t y, uint64_t 
     s += PlusMinusOne(r.x) * ssaaRadius;
     t += PlusMinusOne(r.y) * ssaaRadius;
     Ray viewRay = GetRay(rc.sc->camera, s / (float)rc.opts.width, t / (float)rc.opts.height, r.z, r.w);
-    return CalculateRayColourLooped(rc, viewRay, key, st, scratch);
+    const uint32_t vis = rc.opts.debug_visualisation;
+    if (vis == RT_VIS_NONE) return CalculateRayColourLooped(rc, viewRay, key, st, scratch);
+    if (vis == RT_VIS_BOUNCE_DEPTH) {                                                                   // :251-306
+        int maxDepthReached = -1;
+        int maxAllowedDepth = (int)rc.opts.max_bounce_depth;
+        Ray currentRay = viewRay;
+        scratch.resize((size_t)maxAllowedDepth + 1);
+        for (int currentDepth = 0;; currentDepth++) {
+            if (currentDepth > maxAllowedDepth) { st.bounceLimit++; break; }
+            key.depth = (uint32_t)currentDepth;
+            Found f = TryFindClosestHit(*rc.sc, currentRay, rc.opts.k_min, rc.opts.k_max, key, st);
+            if (f.ok()) {
+                maxDepthReached = currentDepth;
+                scratch[currentDepth] = f.hit;
+                currentRay = Scatter(rc, f.hit, scratch.data(), currentDepth, key);
+                st.scatter++;
+            } else { st.skyRays++; break; }
+        }
+        if (maxDepthReached == -1) return {1, 0, 1};                                                    // Colour.Purple
+        float val = 1 - std::pow(E_F, -((float)(maxDepthReached * maxDepthReached) * std::sqrt((float)maxAllowedDepth)));
+        return ColourLerp({1, 1, 1}, Colour{0, 0, 1} * 0.02f, val);
+    }
+    Found f = TryFindClosestHit(*rc.sc, viewRay, rc.opts.k_min, rc.opts.k_max, key, st);
+    if (!f.ok()) return Black;                                                                          // NoColour
+    const HitRecord& hit = f.hit;
+    switch (vis) {
+        case RT_VIS_NORMALS: { V3 n = (hit.Normal + v3(1.0f)) / 2.0f; return {n.x, n.y, n.z}; }          // :156-162
+        case RT_VIS_FACE_DIRECTION: return hit.OutsideFace ? Colour{0, 1, 0} : Colour{1, 0, 0};         // :163-168
+        case RT_VIS_DISTANCE_CLOSE: { float z = hit.K - rc.opts.k_min; return col(std::pow(E_F, -(0.01f * z * z))); }
+        case RT_VIS_DISTANCE_MID:   { float z = hit.K - rc.opts.k_min; return col(std::pow(E_F, -(0.0001f * z * z))); }
+        case RT_VIS_DISTANCE_FAR:   { float z = hit.K - rc.opts.k_min; return col(std::pow(E_F, -(.000001f * z * z))); }
+        case RT_VIS_UV_COORDS: return {hit.U, hit.V, 1};                                                // :229-233
+        case RT_VIS_PIXEL_COORD_TEXTURE: return UniqueColourFromMaterialHash(hit.Material, std::sin((float)x / 2.0f) * std::sin((float)y / 2.0f) < 0);
+        case RT_VIS_WORLD_COORD_TEXTURE: return UniqueColourFromMaterialHash(hit.Material, std::sin(hit.WorldPoint.x * 40.0f) * std::sin(hit.WorldPoint.y * 40.0f) * std::sin(hit.WorldPoint.z * 40.0f) < 0);
+        case RT_VIS_LOCAL_COORD_TEXTURE: return UniqueColourFromMaterialHash(hit.Material, std::sin(hit.LocalPoint.x * 40.0f) * std::sin(hit.LocalPoint.y * 40.0f) * std::sin(hit.LocalPoint.z * 40.0f) < 0);
+        case RT_VIS_SCATTER_DIRECTION: {                                                                // :221-228 (no builtin material absorbs)
+            Ray sc = Scatter(rc, hit, scratch.data(), 0, key);
+            V3 n = (sc.d + v3(1.0f)) / 2.0f; return {n.x, n.y, n.z};
+        }
+        case RT_VIS_ESTIMATED_LIGHT: {                                                                  // :234-250
+            Colour sum = Black;
+            uint32_t samples = rc.opts.light_sample_count_hint, nl = (uint32_t)rc.sc->lights.size();
+            for (uint32_t i = 0; i < samples; i++)
+                for (uint32_t li = 0; li < nl; li++) sum = sum + CalculateLight(*rc.sc, li, hit, key, i * nl + li, st);
+            return sum / (float)samples;
+        }
+        default: return Black;
+    }
 }
 
 } // namespace
@@ -1142,6 +1200,7 @@ int orc_trace_any(orc_scene* s, const rt_ray* rays, const float* kMin, const flo
 int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride,
                uint32_t n_threads, float* rgb_sum, rt_stats* stats_out) {
     if (!s || !opts || !rgb_sum || opts->width < 1 || opts->height < 1 || opts->light_sample_count_hint < 1) { g_err = "bad render args"; return RT_ERR_INVALID_ARG; }
+    if (opts->debug_visualisation > RT_VIS_BOUNCE_DEPTH || opts->debug_visualisation == RT_VIS_UNDEFINED_TEST) { g_err = "Wrong enum value for debug visualisation"; return RT_ERR_INVALID_ARG; }   // RenderJob.cs:307-308
     RenderCtx rc{&s->sc, *opts};
     if (n_threads < 1) n_threads = 1;
     if (pass_stride < 1) pass_stride = 1;

@@ -208,6 +208,12 @@ class Scene:                       # Core/Scene.cs:9
 # ---------------------------------------------------------------------------------------------------------
 # RenderOptions (Core/RenderOptions.cs).  Validation and messages follow the property setters.
 # ---------------------------------------------------------------------------------------------------------
+class GraphicsDebugVisualisation:
+    """Ararem.RayTracer.Core/Debugging/GraphicsDebugVisualisation.cs:4-61 (same values as rt_debug_vis)."""
+    (None_, Normals, FaceDirection, DistanceFromCamera_Close, DistanceFromCamera_Mid, DistanceFromCamera_Far, UVCoords, PixelCoordDebugTexture,
+     ScatterDirection, LocalCoordDebugTexture, WorldCoordDebugTexture, EstimatedLight, UndefinedTestVisualisation, BounceDepth) = range(14)
+
+
 class RenderOptions:
     def __init__(self, RenderWidth=1920, RenderHeight=1080, KMin=0.001, KMax=math.inf, ConcurrencyLevel=None, Passes=100,
                  InfinitePasses=False, MaxBounceDepth=10, DebugVisualisation=0, LightSampleCountHint=2,

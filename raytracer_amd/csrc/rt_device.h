@@ -611,7 +611,7 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
 // ------------------------------------------------------------------------------------------------
 // HitRecord reconstruction for the winning object (the rest of each TryHit body).
 // ------------------------------------------------------------------------------------------------
-struct HitRec { f3 wp, n; float k, u, v, shader; uint32_t obj, mat; bool outside; };
+struct HitRec { f3 wp, n, lp; float k, u, v, shader; uint32_t obj, mat; bool outside; };    // lp (HitRecord.LocalPoint) only with WANT_UV
 
 RT_FN void sphere_uv(f3 p, float& u, float& v) {                                       // Sphere.cs:78-93
     float theta = acosf(-p.y);
@@ -625,14 +625,14 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
     HitRec h; h.k = c.k; h.obj = c.obj; h.mat = sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
     uint32_t code = sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
     h.wp = point_at(r.o, r.d, c.k);
-    h.n = mk3(0, 0, 0);
+    h.n = mk3(0, 0, 0); h.lp = h.wp;
     switch (type) {
         case RT_HIT_SPHERE: if constexpr (RT_HAS_PRIM(C, RT_HIT_SPHERE)) {                                                            // Sphere.cs:59-70
             float4 s = sc.spheres[idx];
             f3 outN = normalize(h.wp - mk3(s.x, s.y, s.z));
             bool inside = dot(r.d, outN) > 0.0f;
             h.n = inside ? -outN : outN; h.outside = !inside;
-            if (WANT_UV) sphere_uv(outN, h.u, h.v);
+            if (WANT_UV) { sphere_uv(outN, h.u, h.v); h.lp = h.wp - mk3(s.x, s.y, s.z); }
         } break;
         case RT_HIT_QUAD: case RT_HIT_TRIANGLE: if constexpr (RT_HAS_PRIM(C, RT_HIT_QUAD) || RT_HAS_PRIM(C, RT_HIT_TRIANGLE)) {                                        // Quad.cs:100-119
             const float4* q = (type == RT_HIT_QUAD ? sc.quads : sc.triangles) + 4 * idx;
@@ -643,12 +643,14 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                 f3 lp = h.wp - mk3(q0.x, q0.y, q0.z); float4 c1 = q[2], c2 = q[3];
                 h.u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
                 h.v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
+                h.lp = lp;
             }
         } break;
         case RT_HIT_INFINITE_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_INFINITE_PLANE)) {                                                    // InfinitePlane.cs:55-60
             float4 p1 = sc.inf_planes[2 * idx + 1];
             h.n = mk3(p1.x, p1.y, p1.z);
             h.outside = dot(r.d, h.n) < 0;
+            if (WANT_UV) { float4 p0 = sc.inf_planes[2 * idx]; h.lp = h.wp - mk3(p0.x, p0.y, p0.z); }
         } break;
         case RT_HIT_XY_PLANE: case RT_HIT_XZ_PLANE: case RT_HIT_YZ_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_XY_PLANE) || RT_HAS_PRIM(C, RT_HIT_XZ_PLANE) || RT_HAS_PRIM(C, RT_HIT_YZ_PLANE)) {              // XYPlane.cs:69-101
             int axis = type - RT_HIT_XY_PLANE;
@@ -660,6 +662,8 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
             if (WANT_UV) {
                 float a = axis == 2 ? h.wp.y : h.wp.x, b = axis == 0 ? h.wp.y : h.wp.z;
                 h.u = (a - p0.x) / (p0.y - p0.x); h.v = (b - p0.z) / (p0.w - p0.z);
+                float ca = (p0.x + p0.y) / 2.0f, cb = (p0.z + p0.w) / 2.0f;                // XYPlane.cs:28 centre
+                h.lp = h.wp - (axis == 0 ? mk3(ca, cb, planeC) : axis == 1 ? mk3(ca, planeC, cb) : mk3(planeC, ca, cb));
             }
         } break;
         case RT_HIT_DISK: if constexpr (RT_HAS_PRIM(C, RT_HIT_DISK)) {                                                              // Disk.cs:83-97
@@ -675,7 +679,7 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                     u = (u > 0.0f) ? u : 0.0f; u = (u < 1.0f) ? u : 1.0f;
                     v = (v > 0.0f) ? v : 0.0f; v = (v < 1.0f) ? v : 1.0f;
                 }
-                h.u = u; h.v = v;
+                h.u = u; h.v = v; h.lp = lp;
             }
         } break;
         case RT_HIT_BOX: if constexpr (RT_HAS_PRIM(C, RT_HIT_BOX)) {                                                               // Box.cs:147-182
@@ -689,6 +693,11 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
             else nrm = mk3(r1.z, r1.w, r2.x) * bs.s.z;
             h.n = normalize(nrm);
             h.outside = dot(r.d, nrm) < 0.0f;
+            if (WANT_UV) {                                                                // Transform(worldPoint, WorldToBoxTransform), Box.cs:181
+                float4 m0 = b[0], m1 = b[1], m2 = b[2];
+                h.lp = mk3((h.wp.x * m0.x) + (h.wp.y * m0.w) + (h.wp.z * m1.z) + m2.y, (h.wp.x * m0.y) + (h.wp.y * m1.x) + (h.wp.z * m1.w) + m2.z,
+                           (h.wp.x * m0.z) + (h.wp.y * m1.y) + (h.wp.z * m2.x) + m2.w);
+            }
         } break;
         case RT_HIT_CAPSULE: if constexpr (RT_HAS_PRIM(C, RT_HIT_CAPSULE)) {                                                           // Capsule.cs:114-140, CapNormal :186-191
             const float4* cp = sc.capsules + 5 * idx;
@@ -706,18 +715,20 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                 h.u = (rawU + PI_F) / 6.2831855f;
                 float lo = -radius, hi = distance(P1, P2) + radius;
                 h.v = (q.z - lo) / (hi - lo);
+                h.lp = h.wp - lerp3(P1, P2, 0.5f);
             }
         } break;
         case RT_HIT_CYLINDER: if constexpr (RT_HAS_PRIM(C, RT_HIT_CYLINDER)) {                                                          // Cylinder.cs:100-104
             float k; f3 nrm = mk3(0, 0, 0);
             try_cylinder(sc.cylinders + 2 * idx, r, c.k, c.k, k, nrm, false);
             h.n = nrm; h.outside = !(dot(r.d, nrm) > 0.0f);
+            if (WANT_UV) { float4 c0 = sc.cylinders[2 * idx], c1 = sc.cylinders[2 * idx + 1]; h.lp = h.wp - lerp3(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), 0.5f); }
         } break;
         case RT_HIT_MEDIUM: if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {                                                            // ConstantDensityMedium.cs:61-67
             float4 u = rng_draw(key, depth, SLOT_MEDIUM, c.obj);
             h.wp = point_at(r.o, r.d, c.aux);         // sic: measured from the ray origin
             h.n = on_unit_sphere(u.y, u.z, u.w);
-            h.shader = c.aux; h.outside = true;
+            h.shader = c.aux; h.outside = true; h.lp = h.wp;
         } break;
         default: break;
     }

@@ -46,6 +46,7 @@ struct RenderDev {
     uint64_t seed;
     float k_min, k_max;
     uint32_t max_depth, light_samples;
+    uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
 
 RT_FN uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -133,7 +134,22 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
 // reserves both output ranges with ONE atomic each, and then shades; positions inside the tile keep the input order.
 constexpr int SHADE_ITEMS = 8;
 
-template <class C>
+// RenderJob.UniqueColourFromMaterialHash, RenderJob.cs:317-328 (see rt_hip.h for the stand-in hash)
+RT_FN col3 material_hash_colour(uint32_t material, bool alternate) {
+    uint32_t hash = (material + 1u) * 2654435761u;
+    int o = alternate ? 1 : 0;
+    return mkc((float)((hash >> (8 * (o + 0))) & 0xFFu) / 255.0f, (float)((hash >> (8 * (o + 1))) & 0xFFu) / 255.0f, (float)((hash >> (8 * (o + 2))) & 0xFFu) / 255.0f);
+}
+// the bounce-depth picture of a finished path, RenderJob.cs:303-305
+RT_FN col3 bounce_depth_colour(int maxDepthReached, uint32_t maxAllowedDepth) {
+    if (maxDepthReached < 0) return mkc(1, 0, 1);
+    float val = 1 - powf(E_F, -((float)(maxDepthReached * maxDepthReached) * sqrtf((float)maxAllowedDepth)));
+    return (mkc(1, 1, 1) * (1.0f - val)) + ((mkc(0, 0, 1) * 0.02f) * val);
+}
+
+// VIS = RenderOptions.DebugVisualisation != None (RenderJob.cs:148-309): the same kernel decides a debug colour from the first hit
+// instead of shading it (the host runs one bounce then, except for BounceDepth which runs the whole loop without colours).
+template <class C, bool VIS = false>
 __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
@@ -154,7 +170,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
               uint32_t obj = __float_as_uint(rd.hit[j].y);
               hit = obj != RT_NO_HIT;
               lit = hit && sc.n_lights > 0;
-              if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) { if (hit) lit = lit && sc.materials[sc.obj_material[obj]].type != RT_MAT_VOLUMETRIC; }
+              if constexpr (VIS) lit = lit && rd.vis == RT_VIS_ESTIMATED_LIGHT;          // the only visualisation that samples lights, for every material
+              else if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) { if (hit) lit = lit && sc.materials[sc.obj_material[obj]].type != RT_MAT_VOLUMETRIC; }
           }
           const bool surv = hit && can_survive;
           unsigned long long bs = __ballot(surv), bl = __ballot(lit);
@@ -197,13 +214,14 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
             Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
             if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) c.aux = rd.hit_aux[j];
             if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450
-                L = L + (T * sky_colour(sc, r.d));
+                if constexpr (VIS) { L = rd.vis == RT_VIS_BOUNCE_DEPTH ? bounce_depth_colour((int)depth - 1, rd.max_depth) : mkc(0, 0, 0); }   // NoColour / :303-305
+                else L = L + (T * sky_colour(sc, r.d));
                 sky++; samples++;
                 if (depth > 0) hist_miss++;                                              // RenderJob.cs:458: maxDepthReached = depth - 1
                 rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
             } else {
                 RngKey key = path_key(rd, id);
-                HitRec h = finalize_hit<C, false>(sc, r, c, key, depth);
+                HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth);
                 const rt_material* m = sc.materials + h.mat;
                 uint32_t prev = __float_as_uint(a3.y), first = __float_as_uint(a3.z);
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
@@ -269,6 +287,24 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
                     } break;
                 }
                 scat++;                                                                   // RenderJob.cs:439
+                if constexpr (VIS) {
+                    const uint32_t pix = id % rd.n_pixels, px = pix % rd.width, py = pix / rd.width;
+                    float z = h.k - rd.k_min;
+                    switch (rd.vis) {
+                        case RT_VIS_NORMALS: { f3 n = (h.n + splat(1.0f)) / 2.0f; L = mkc(n.x, n.y, n.z); } break;
+                        case RT_VIS_FACE_DIRECTION: L = h.outside ? mkc(0, 1, 0) : mkc(1, 0, 0); break;
+                        case RT_VIS_DISTANCE_CLOSE: { float v = powf(E_F, -(0.01f * z * z)); L = mkc(v, v, v); } break;
+                        case RT_VIS_DISTANCE_MID:   { float v = powf(E_F, -(0.0001f * z * z)); L = mkc(v, v, v); } break;
+                        case RT_VIS_DISTANCE_FAR:   { float v = powf(E_F, -(.000001f * z * z)); L = mkc(v, v, v); } break;
+                        case RT_VIS_UV_COORDS: L = mkc(h.u, h.v, 1); break;
+                        case RT_VIS_PIXEL_COORD_TEXTURE: L = material_hash_colour(h.mat, sinf((float)px / 2.0f) * sinf((float)py / 2.0f) < 0); break;
+                        case RT_VIS_WORLD_COORD_TEXTURE: L = material_hash_colour(h.mat, sinf(h.wp.x * 40.0f) * sinf(h.wp.y * 40.0f) * sinf(h.wp.z * 40.0f) < 0); break;
+                        case RT_VIS_LOCAL_COORD_TEXTURE: L = material_hash_colour(h.mat, sinf(h.lp.x * 40.0f) * sinf(h.lp.y * 40.0f) * sinf(h.lp.z * 40.0f) < 0); break;
+                        case RT_VIS_SCATTER_DIRECTION: { f3 n = (nr.d + splat(1.0f)) / 2.0f; L = mkc(n.x, n.y, n.z); } break;
+                        case RT_VIS_ESTIMATED_LIGHT: L = mkc(0, 0, 0); W = mkc(1, 1, 1); break;       // k_shadow adds sum / samples
+                        default: L = bounce_depth_colour((int)depth, rd.max_depth); break;            // BounceDepth: used if the path ends here (bounce limit)
+                    }
+                }
                 if (shadow) {
                     rd.sh[0][p1] = make_float4(h.wp.x, h.wp.y, h.wp.z, h.n.x);
                     rd.sh[1][p1] = make_float4(h.n.y, h.n.z, W.r, W.g);
@@ -314,7 +350,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(Scene
         f3 in = mk3(0, 0, 0);
         if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
             m = sc.materials + sc.obj_material[__float_as_uint(h2.w)];
-            phong = m->type == RT_MAT_PHONG;
+            phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;      // EstimatedLight is the plain light sum whatever the material (RenderJob.cs:234-250)
             if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
         }
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;

@@ -443,7 +443,8 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->k_min < 0 || std::isnan(o->k_min)) return fail(RT_ERR_INVALID_ARG, "KMin cannot have a value of less than 0");                   // :74
     if (o->k_max < o->k_min || std::isnan(o->k_max)) return fail(RT_ERR_INVALID_ARG, "KMax cannot have a value of less than 0 or less than KMin"); // :86
     if (o->light_sample_count_hint < 1) return fail(RT_ERR_INVALID_ARG, "Must have at least 1 sample per light");                         // :160
-    if (o->debug_visualisation != RT_VIS_NONE) return fail(RT_ERR_UNSUPPORTED, "debug visualisation %u is not implemented on the device", o->debug_visualisation);
+    if (o->debug_visualisation > RT_VIS_BOUNCE_DEPTH || o->debug_visualisation == RT_VIS_UNDEFINED_TEST)
+        return fail(RT_ERR_INVALID_ARG, "Wrong enum value for debug visualisation (%u)", o->debug_visualisation);                           // RenderJob.cs:307-308
     if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
     if (o->device >= 0 && o->device != s->device) return fail(RT_ERR_INVALID_ARG, "render device %d differs from the scene's device %d", o->device, s->device);
     const uint64_t n_pixels = (uint64_t)o->width * o->height;
@@ -505,6 +506,7 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
         rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
         rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+        rd.vis = o->debug_visualisation;
     }
     r->rd = r->slots[0].rd;
     r->stats_host.assign(ST_COUNT, 0);
@@ -537,16 +539,23 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     hipStream_t st = sl.stream;
     const KernelSet* ks = s->ks;
     const uint32_t n_cnt = r->opts.max_bounce_depth + 2;
+    // debug visualisations look at the first hit only (RenderJob.cs:154), except BounceDepth which runs the bounce loop
+    const uint32_t vis = r->opts.debug_visualisation;
+    const bool first_hit_only = vis != RT_VIS_NONE && vis != RT_VIS_BOUNCE_DEPTH;
+    const uint32_t max_depth = first_hit_only ? 0u : r->opts.max_bounce_depth;
+    if (first_hit_only) rd.max_depth = 0;
+    auto shade_kernel = vis != RT_VIS_NONE ? k_shade<CfgAll, true> : ks->shade;
+    const bool trace_shadows = s->n_lights && (vis == RT_VIS_NONE || vis == RT_VIS_ESTIMATED_LIGHT);
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
     const size_t lds = stack_bytes(s);
     { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
-    for (uint32_t depth = 0; depth <= r->opts.max_bounce_depth; depth++) {
+    for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
           if (s->use_lds) hipLaunchKernelGGL(ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
-        { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(ks->shade, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
-        if (s->n_lights) { Timed t(r, RT_K_SHADOW, st);
+        { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
+        if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (s->use_lds) hipLaunchKernelGGL(ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }

@@ -158,9 +158,9 @@ def test_rejections_through_the_c_abi(pairs):
     sc, flat, dev, orc = pairs("Sphere")
     lib = capi.load()
     bad = rt.render_job.make_opts(RenderOptions(RenderWidth=8, RenderHeight=8))
-    bad.debug_visualisation = 5
+    bad.debug_visualisation = 12                                                   # UndefinedTestVisualisation: the reference throws (RenderJob.cs:307-308)
     h = C.c_void_p()
-    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -2        # RT_ERR_UNSUPPORTED
+    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -1        # RT_ERR_INVALID_ARG
     bad.debug_visualisation = 0; bad.light_sample_count_hint = 0
     assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -1
     # an unknown hittable type is rejected, not emulated
@@ -168,3 +168,23 @@ def test_rejections_through_the_c_abi(pairs):
     objs = np.ctypeslib.as_array(C.cast(flat2.desc.objects, C.POINTER(C.c_uint32)), shape=(9,))
     objs[0] = 77
     assert lib.rt_scene_create(C.byref(flat2.desc), -1, C.byref(h)) == -2
+
+
+VIS = rt.GraphicsDebugVisualisation
+VIS_NAMES = {v: k for k, v in vars(VIS).items() if isinstance(v, int) and not k.startswith("_")}
+
+
+@pytest.mark.parametrize("name", ["Demo", "Zoo", "Testing", "CornellBox"])
+@pytest.mark.parametrize("vis", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
+def test_debug_visualisations_match_the_oracle(pairs, name, vis):
+    """RenderJob.cs:148-309.  Every visualisation is a deterministic function of the first hit (BounceDepth: of the bounce loop),
+    so the sums agree pixel for pixel up to libm ulps; the checker textures and the face direction flip where sin() or a dot product
+    is within an ulp of zero, hence a fraction rather than all pixels."""
+    sc, flat, dev, orc = pairs(name)
+    opt = RenderOptions(RenderWidth=96, RenderHeight=54, Passes=3, MaxBounceDepth=6, LightSampleCountHint=2, Seed=77, DebugVisualisation=vis)
+    job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+    got, n = job.ReadAccum(); job.Dispose()
+    ref, _ = orc.render(opt, threads=8)
+    assert n == 3 and np.isfinite(got).all()
+    close = (np.abs(got - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2) + 1e-5).all(axis=2).mean()
+    assert close > 0.985, f"{VIS_NAMES[vis]} on {name}: only {close:.4f} of pixels match"
