@@ -133,6 +133,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
 // for light samples follows from its hit alone, so a block first reads the hit ids of SHADE_ITEMS x BLOCK positions, counts,
 // reserves both output ranges with ONE atomic each, and then shades; positions inside the tile keep the input order.
 constexpr int SHADE_ITEMS = 8;
+#ifndef RT_SHADE_MIN_WAVES
+#define RT_SHADE_MIN_WAVES 1
+#endif
+constexpr int SHADE_MIN_WAVES = RT_SHADE_MIN_WAVES;
 
 // RenderJob.UniqueColourFromMaterialHash, RenderJob.cs:317-328 (see rt_hip.h for the stand-in hash)
 RT_FN col3 material_hash_colour(uint32_t material, bool alternate) {
@@ -150,7 +154,7 @@ RT_FN col3 bounce_depth_colour(int maxDepthReached, uint32_t maxAllowedDepth) {
 // VIS = RenderOptions.DebugVisualisation != None (RenderJob.cs:148-309): the same kernel decides a debug colour from the first hit
 // instead of shading it (the host runs one bounce then, except for BounceDepth which runs the whole loop without colours).
 template <class C, bool VIS = false>
-__global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
     unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0;
@@ -186,16 +190,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
       }
       __syncthreads();
       uint32_t row_s = bases[0], row_l = bases[1];
-      // the next position's state is in flight while this one is shaded (the loads are the kernel's critical resource)
-      float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0; float2 nh = make_float2(0, 0);
-      { const uint32_t j0 = tile + threadIdx.x;
-        if (j0 < n) { n0 = rd.st[cur][0][j0]; n1 = rd.st[cur][1][j0]; n2 = rd.st[cur][2][j0]; n3 = rd.st[cur][3][j0]; nh = rd.hit[j0]; } }
 #pragma unroll 1
       for (int item = 0; item < SHADE_ITEMS; item++) {
         const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
-        const float4 a0 = n0, a1 = n1, a2 = n2, a3 = n3; const float2 hk = nh;
-        { const uint32_t jn = j + BLOCK;
-          if (item + 1 < SHADE_ITEMS && jn < n) { n0 = rd.st[cur][0][jn]; n1 = rd.st[cur][1][jn]; n2 = rd.st[cur][2][jn]; n3 = rd.st[cur][3][jn]; nh = rd.hit[jn]; } }
         const bool survive = (m_surv >> item) & 1u, shadow = (m_shad >> item) & 1u;
         // this path's output positions: rows before, waves before in the row, lanes before in the wave
         uint32_t p0 = row_s, p1 = row_l;
@@ -207,6 +204,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
         p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
         p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
         if (j < n) {
+            const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j], a3 = rd.st[cur][3][j];
+            const float2 hk = rd.hit[j];
             Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
             col3 T = mkc(a1.z, a1.w, a2.x);
             col3 L = mkc(a2.y, a2.z, a2.w);
@@ -332,18 +331,17 @@ __global__ void __launch_bounds__(BLOCK) k_shade(SceneDev sc, RenderDev rd, uint
 
 // Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
 template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
-    unsigned long long rays = 0, nodes = 0, prims = 0;
+    uint32_t rays = 0, nodes = 0, prims = 0;          // per thread: at most a few thousand requests x rays x nodes
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     for (uint32_t p = blockIdx.x * TB + threadIdx.x; p < n; p += gridDim.x * TB) {
         float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
         f3 wp = mk3(h0.x, h0.y, h0.z);
         f3 nrm = mk3(h0.w, h1.x, h1.y);
-        col3 W = mkc(h1.z, h1.w, h2.x);
-        const uint32_t id = __float_as_uint(h2.y), dst = __float_as_uint(h2.z);
+        const uint32_t id = __float_as_uint(h2.y);                  // (the weight W and the destination are re-read after the traversals: 4 registers fewer across them)
         RngKey key = path_key(rd, id);
         const rt_material* m = nullptr;
         bool phong = false;
@@ -384,6 +382,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow(Scene
         }
         float S = (float)rd.light_samples, invS = rcp_fast(S);
         sum = sum * invS;
+        const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
+        const col3 W = mkc(e1.z, e1.w, e2.x);
+        const uint32_t dst = __float_as_uint(e2.z);
         col3 add;
         if (!phong) add = W * sum;
         else { spec_sum = spec_sum * invS; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
