@@ -458,6 +458,23 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     const uint64_t target_paths = 128ull << 20;
     uint32_t ppb = o->passes_per_batch ? o->passes_per_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
     if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
+    // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob)
+    int n_slots = 2;
+    if (const char* e = getenv("RT_HIP_SLOTS")) n_slots = std::max(1, std::min(MAX_SLOTS, atoi(e)));
+    // path state: float4 arrays (2 x 4 state, 1 out, 3 (+1) shadow), then hit (float2) and hit_aux (float).  passes_per_batch is an
+    // upper bound: when the device cannot hold it (another job, a smaller card) the batch is halved until it fits.
+    const bool has_phong = (s->ks->mats >> RT_MAT_PHONG) & 1u, has_medium = (s->ks->prims >> RT_HIT_MEDIUM) & 1u;
+    const size_t n_f4 = 8 + 1 + 3 + (has_phong ? 1 : 0);
+    const size_t bytes_per_path = n_f4 * sizeof(float4) + sizeof(float2) + (has_medium ? sizeof(float) : 0);
+    for (;;) {
+        bool ok = true;
+        for (int si = 0; si < n_slots && ok; si++) ok = r->slots[si].f32_pool.alloc((size_t)(n_pixels * ppb) * bytes_per_path) == hipSuccess;
+        if (ok) break;
+        (void)hipGetLastError();
+        for (int si = 0; si < n_slots; si++) (void)r->slots[si].f32_pool.alloc(0);
+        if (ppb == 1) return fail(RT_ERR_OUT_OF_MEMORY, "not enough device memory for the path state of one pass (%zu bytes per slot)", (size_t)n_pixels * bytes_per_path);
+        ppb = std::max<uint32_t>(1, ppb / 2);
+    }
     r->passes_per_batch = ppb;
     const size_t P = (size_t)(n_pixels * ppb);
     r->max_paths = P;
@@ -465,9 +482,6 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->stream) r->stream = (hipStream_t)o->stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
 
-    // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob); one when the whole job is a single batch
-    int n_slots = 2;
-    if (const char* e = getenv("RT_HIP_SLOTS")) n_slots = std::max(1, std::min(MAX_SLOTS, atoi(e)));
     r->n_slots = n_slots;
     HIP_TRY(r->stats.alloc(ST_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(r->stats.p, 0, r->stats.bytes, r->stream));
@@ -482,15 +496,11 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
 
     const uint32_t n_cnt = o->max_bounce_depth + 2;
-    const bool has_phong = (s->ks->mats >> RT_MAT_PHONG) & 1u, has_medium = (s->ks->prims >> RT_HIT_MEDIUM) & 1u;
     for (int si = 0; si < n_slots; si++) {
         Slot& sl = r->slots[si];
         if (si == 0) sl.stream = r->stream;
         else HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_acc[si], hipEventDisableTiming));
-        // float4 arrays: 2 x 4 state, 1 out, 3 (+1) shadow ; then hit (float2) and hit_aux (float)
-        const size_t n_f4 = 8 + 1 + 3 + (has_phong ? 1 : 0);
-        HIP_TRY(sl.f32_pool.alloc(P * (n_f4 * sizeof(float4) + sizeof(float2) + (has_medium ? sizeof(float) : 0))));
         HIP_TRY(sl.counters.alloc(2 * n_cnt * sizeof(uint32_t)));
         RenderDev& rd = sl.rd;
         float4* f = sl.f32_pool.as<float4>();
