@@ -10,10 +10,10 @@ from raytracer_amd.core import RenderOptions
 
 CONFIGS = {
     "c1": ("Demo 480x270 depth 8", bs.Demo, 480, 270, 64, 8, 2, 64),
-    "c2": ("Night Spheres 1920x1080 depth 10", bs.Testing, 1920, 1080, 64, 10, 2, 8),
-    "c3": ("Cornell (I=1.0, direct) 1920x1080 depth 32", lambda: bs.CornellBox(1.0, True), 1920, 1080, 32, 32, 2, 8),
-    "c4": ("Triangle mesh 4 999 122 tris 3840x2160 depth 8", bs.TriangleMesh, 3840, 2160, 8, 8, 2, 2),
-    "c5": ("100 k spheres + 64 lights 3840x2160 depth 10", bs.ManySpheresManyLights, 3840, 2160, 4, 10, 1, 1),
+    "c2": ("Night Spheres 1920x1080 depth 10", bs.Testing, 1920, 1080, 128, 10, 2, 64),
+    "c3": ("Cornell (I=1.0, direct) 1920x1080 depth 32", lambda: bs.CornellBox(1.0, True), 1920, 1080, 64, 32, 2, 32),
+    "c4": ("Triangle mesh 4 999 122 tris 3840x2160 depth 8", bs.TriangleMesh, 3840, 2160, 32, 8, 2, 16),
+    "c5": ("100 k spheres + 64 lights 3840x2160 depth 10", bs.ManySpheresManyLights, 3840, 2160, 4, 10, 1, 2),
 }
 
 def main():
