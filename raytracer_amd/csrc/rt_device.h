@@ -451,7 +451,11 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 //   HbmTree: nodes and primitives come through the vector cache (L1 -> L2 -> Infinity Cache -> HBM); 32-bit stack column in LDS.
 //   LdsTree: the whole tree and the sphere table live in the workgroup's LDS (scenes of a few hundred objects): a divergent
 //            64-lane node fetch costs LDS cycles instead of 64 cache-line lookups in the texture path; 16-bit stack column.
+#ifndef RT_TRAV_VOTE
+#define RT_TRAV_VOTE 1
+#endif
 struct HbmTree {
+    static constexpr bool vote = RT_TRAV_VOTE;
     int* stack; int stride;
     RT_FN void node(const SceneDev& sc, int i, float4& q0, float4& q1, float4& q2, int2& ch) const {
         const Node* np = sc.nodes + i;
@@ -471,6 +475,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
     return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
 }
 struct LdsTree {
+    static constexpr bool vote = false;      // rays of equal cost: the votes only cost instructions here
     const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
     unsigned short* stack; int stride;
     RT_FN void node(const SceneDev&, int i, float4& a, float4& b, float4& c, int2& d) const { a = q0[i]; b = q1[i]; c = q2[i]; d = ch[i]; }
@@ -543,6 +548,17 @@ RT_FN void leaf_advance(const Tree& tree, int& cur, int& pend, int& sp) {
     }
 }
 
+// The wave's vote on what to do next (HbmTree scenes).  The plain rule "box tests until every lane holds a leaf" lets one lane
+// that descends 30 levels without meeting a leaf hold 63 lanes that each sit on two: on the 5 M-triangle mesh 9 of 64 lanes
+// were busy on average.  So the lanes that can step are counted against the lanes that cannot move until a leaf of theirs is
+// tested, and the majority decides; the leaf round that follows serves every lane with a parked leaf, the steppers too.
+// The order of a ray's own leaf tests is unchanged, and testing one earlier only shrinks kMax earlier: same result.
+RT_FN bool step_vote(int cur, int pend) {
+    const int n_step = __popcll(__ballot(cur >= 0));
+    const int n_blocked = __popcll(__ballot(cur < 0 && pend != TRAV_DONE));
+    return n_step != 0 && n_step >= n_blocked;
+}
+
 template <class C, class Tree>
 RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
@@ -556,7 +572,8 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
         const f3 invD = splat(1.0f) / r.d;
         int sp = 0, cur = 0, pend = TRAV_DONE;
         for (;;) {
-            while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }   // every lane does box tests here
+            if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); } }
+            else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }   // every lane does box tests here
             if (pend != TRAV_DONE) {                               // leaves: most lanes arrive here with one parked
                 uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
                 if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
@@ -597,7 +614,8 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
     const f3 invD = splat(1.0f) / r.d;
     int sp = 0, cur = 0, pend = TRAV_DONE;
     for (;;) {
-        while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
+        if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); } }
+        else while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
         if (pend != TRAV_DONE) {
             cnt.prims++;
             if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) return true;

@@ -128,6 +128,91 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
     stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
 }
 
+// Persistent-lane closest hit.  In scenes where the cost of a ray has a heavy tail (a bounce ray skimming a 5 M-triangle terrain
+// visits thousands of nodes, its 63 wave-mates a few dozen: 7 of 64 lanes busy on average) a lane must not wait for its wave.
+// Every lane owns a strided series of rays; the wave runs the same postponed-leaf loop, and after each leaf round it votes
+// (ballot + popcount): once fewer than REFILL_BELOW lanes are still traversing and at least REFILL_MIN_TAKERS idle lanes have
+// another ray to fetch, the idle lanes store their result and start their next ray.  All control flow is wave-uniform and the
+// result of a ray does not depend on the schedule.  (On Night Spheres, whose rays cost about the same, the votes and the
+// partial-wave fetch phases lose to the plain loop above: 17.1 vs 15.0 ms per 184 M rays; the host picks per scene.)
+#ifndef RT_REFILL_BELOW
+#define RT_REFILL_BELOW 44
+#define RT_REFILL_MIN_TAKERS 8
+#endif
+constexpr int REFILL_BELOW = RT_REFILL_BELOW, REFILL_MIN_TAKERS = RT_REFILL_MIN_TAKERS;
+
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
+    const uint32_t n = rd.qcount[depth];
+    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
+    const float kMin = rd.k_min, kMax = rd.k_max;
+    const uint32_t stride = gridDim.x * TB;
+    uint32_t j = blockIdx.x * TB + threadIdx.x, my_j = 0;
+    uint32_t rays = 0, nodes = 0, prims = 0;
+    bool active = false;                 // this lane holds a ray (possibly finished and waiting for its store)
+    Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
+    f3 invD = mk3(0, 0, 0);
+    Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
+    int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
+    for (;;) {
+        // ---- store / fetch for every lane that is not traversing
+        if (cur == TRAV_DONE && pend == TRAV_DONE) {
+            if (active) {
+                if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
+                    if (!ray_has_nan(r)) {
+                        RngKey key = path_key(rd, __float_as_uint(g3[my_j].x));        // only a medium draws random numbers
+                        for (uint32_t i = 0; i < sc.n_media; i++) {
+                            uint32_t obj = sc.media[i], code = sc.obj_code[obj];
+                            float k, aux; prims++;
+                            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+                        }
+                    }
+                    rd.hit_aux[my_j] = best.aux;
+                }
+                // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
+                if (best.obj != RT_NO_HIT && !((best.k >= kMin) && (best.k <= kMax))) best.obj = RT_NO_HIT;
+                rd.hit[my_j] = make_float2(best.k, __uint_as_float(best.obj));
+                active = false;
+            }
+            if (j < n) {
+                float4 a = g0[j], b = g1[j];
+                r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
+                my_j = j; j += stride; rays++;
+                best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
+                sp = 0; active = true;
+                if (!ray_has_nan(r)) {
+                    for (uint32_t i = 0; i < sc.n_unbounded; i++) {
+                        uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
+                        float k; prims++;
+                        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                    }
+                    if (sc.n_nodes) { invD = splat(1.0f) / r.d; cur = 0; }
+                }
+            }
+        }
+        if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
+            if (!__any(active || j < n)) break;          // nothing traversing, nothing to store, nothing to fetch
+            continue;                                    // (rays that were finished at fetch time: store them, fetch again)
+        }
+        // ---- traverse until too few lanes are busy
+        for (;;) {
+            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }
+            if (pend != TRAV_DONE) {
+                uint32_t obj = (uint32_t)~pend; float k; prims++;
+                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                leaf_advance(tree, cur, pend, sp);
+            }
+            const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
+            const int n_busy = __popcll(__ballot(busy));
+            if (n_busy == 0) break;
+            if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && j < n)) >= REFILL_MIN_TAKERS) break;
+        }
+    }
+    stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
+}
+
 // Output positions.  A same-address returning atomic is serviced about every 10 ns chip-wide, so a reservation per wave
 // (260 k per 16.6 M paths) made the kernel 8x slower than its memory traffic.  Whether a path survives and whether it asks
 // for light samples follows from its hit alone, so a block first reads the hit ids of SHADE_ITEMS x BLOCK positions, counts,
@@ -480,6 +565,7 @@ struct KernelSet {
     void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
     void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
     // LdsTree forms (null when the variant has none)
+    void (*closest_persistent)(SceneDev, RenderDev, uint32_t);     // heavy-tailed scenes (see k_closest_persistent)
     void (*closest_lds)(SceneDev, RenderDev, uint32_t);
     void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
@@ -487,7 +573,7 @@ struct KernelSet {
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
-                nullptr, nullptr, nullptr, nullptr};
+                k_closest_persistent<C, false>, nullptr, nullptr, nullptr, nullptr};
     if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }

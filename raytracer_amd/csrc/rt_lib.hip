@@ -77,6 +77,7 @@ struct rt_scene {
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
     DevBuf lds_image;
     uint32_t n_objects = 0, n_lights = 0;
     int n_cu = 256;
@@ -358,6 +359,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                 HIP_TRY(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree_bytes_for(image_bytes, s->stack_depth, i < 2 ? LDS_BLOCK_CLOSEST : LDS_BLOCK_SHADOW)));
         }
     }
+    // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 894 Msamples/s with
+    // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
+    { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && nodes.size() * sizeof(Node) > (64u << 20)); }
     *out = s.release();
     return RT_OK;
 }
@@ -563,7 +567,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
           if (s->use_lds) hipLaunchKernelGGL(ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
-          else hipLaunchKernelGGL(ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+          else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (s->use_lds) hipLaunchKernelGGL(ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
