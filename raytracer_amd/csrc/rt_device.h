@@ -454,6 +454,13 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 #ifndef RT_TRAV_VOTE
 #define RT_TRAV_VOTE 1
 #endif
+#ifndef RT_VOTE_A
+#define RT_VOTE_A 1
+#define RT_VOTE_B 3
+#endif
+#ifndef RT_LDS_VOTE
+#define RT_LDS_VOTE 0
+#endif
 struct HbmTree {
     static constexpr bool vote = RT_TRAV_VOTE;
     int* stack; int stride;
@@ -475,7 +482,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
     return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
 }
 struct LdsTree {
-    static constexpr bool vote = false;      // rays of equal cost: the votes only cost instructions here
+    static constexpr bool vote = RT_LDS_VOTE;      // rays of equal cost: the votes only cost instructions here
     const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
     unsigned short* stack; int stride;
     RT_FN void node(const SceneDev&, int i, float4& a, float4& b, float4& c, int2& d) const { a = q0[i]; b = q1[i]; c = q2[i]; d = ch[i]; }
@@ -556,7 +563,7 @@ RT_FN void leaf_advance(const Tree& tree, int& cur, int& pend, int& sp) {
 RT_FN bool step_vote(int cur, int pend) {
     const int n_step = __popcll(__ballot(cur >= 0));
     const int n_blocked = __popcll(__ballot(cur < 0 && pend != TRAV_DONE));
-    return n_step != 0 && n_step >= n_blocked;
+    return n_step != 0 && n_step * RT_VOTE_A >= n_blocked * RT_VOTE_B;
 }
 
 template <class C, class Tree>

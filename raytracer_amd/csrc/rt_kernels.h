@@ -139,10 +139,13 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
 #define RT_REFILL_BELOW 44
 #define RT_REFILL_MIN_TAKERS 8
 #endif
+#ifndef RT_CP_WAVES
+#define RT_CP_WAVES 1
+#endif
 constexpr int REFILL_BELOW = RT_REFILL_BELOW, REFILL_MIN_TAKERS = RT_REFILL_MIN_TAKERS;
 
 template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
@@ -482,6 +485,121 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k
     stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
 }
 
+// Persistent-lane k_shadow (same reasoning as k_closest_persistent).  A request's rays are traced one after the other by its
+// lane, and an occluded ray ends at its first hit: with 64 lights the lane whose rays all reach their light sets the pace of the
+// wave 64 times per request.  Here a lane that has finished a ray accounts for it, draws the next one of its request (or writes
+// the request's sum and takes the next request) while the rest of the wave keeps traversing; the votes are those of
+// k_closest_persistent.  Per request the rays, their order and the order of the additions are the same as in k_shadow: same bits.
+template <class C, bool LDS>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
+    const uint32_t n = rd.sqcount[depth];
+    const uint32_t n_lights = sc.n_lights, per_request = rd.light_samples * n_lights;
+    const uint32_t stride = gridDim.x * TB;
+    float4* next_l = rd.st[(depth & 1) ^ 1][2];
+    uint32_t rays = 0, nodes = 0, prims = 0;
+    uint32_t p_next = blockIdx.x * TB + threadIdx.x, p = 0, q = 0, li = 0;      // q: index of the request's ray in flight, li = q mod n_lights
+    bool have = false, flying = false, occluded = false, second = false;       // second: the Phong material's unattenuated ray of the same light
+    f3 wp = mk3(0, 0, 0), nrm = mk3(0, 0, 1), in = mk3(0, 0, 0);
+    RngKey key = path_key(rd, 0);
+    const rt_material* m = nullptr; bool phong = false;
+    col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0);
+    Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
+    f3 invD = mk3(0, 0, 0);
+    float kMin = 0, kMax = 0;
+    int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
+    if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
+    for (;;) {
+        if (cur == TRAV_DONE && pend == TRAV_DONE) {
+            if (flying) {                                                       // ---- account for the finished ray
+                flying = false;
+                const rt_light* l = sc.lights + li;
+                bool advance = true;
+                if (!second) {
+                    col3 c = mkc(0, 0, 0);
+                    if (!occluded && !(kMax > l->cutoff_radius)) {
+                        float scale = attenuation(l, kMax * rcp_fast(l->attenuation_radius));
+                        scale = maxf_net(scale, 0);
+                        c = mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
+                    }
+                    if (!phong) sum = sum + c;
+                    else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) { cdd = c * fabsf(dot(r.d, nrm)); second = true; advance = false; }
+                } else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {              // PhongMaterial.cs:42-56
+                    col3 c2 = occluded ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
+                    f3 rl = reflect(r.d, -nrm);
+                    float sd = fabsf(dot(in, rl));
+                    spec_sum = spec_sum + (c2 * powf(sd, powf(2.0f, m->f[9])));
+                    sum = sum + cdd;
+                    second = false;
+                }
+                if (advance) { q++; li++; if (li == n_lights) li = 0; }
+                if (q == per_request) {                                         // ---- the request is complete: add its light to the path
+                    float S = (float)rd.light_samples, invS = rcp_fast(S);
+                    sum = sum * invS;
+                    const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
+                    const col3 W = mkc(e1.z, e1.w, e2.x);
+                    const uint32_t dst = __float_as_uint(e2.z), id = __float_as_uint(e2.y);
+                    col3 add;
+                    if (!phong) add = W * sum;
+                    else { spec_sum = spec_sum * invS; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
+                    float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
+                    float4 t = *tgt;
+                    if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
+                    *tgt = t;
+                    have = false;
+                }
+            }
+            if (!have && p_next < n) {                                          // ---- next request
+                p = p_next; p_next += stride;
+                float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
+                wp = mk3(h0.x, h0.y, h0.z); nrm = mk3(h0.w, h1.x, h1.y);
+                key = path_key(rd, __float_as_uint(h2.y));
+                if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
+                    m = sc.materials + sc.obj_material[__float_as_uint(h2.w)];
+                    phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;
+                    if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+                }
+                sum = mkc(0, 0, 0); spec_sum = mkc(0, 0, 0);
+                q = 0; li = 0; second = false; have = true;
+            }
+            if (have) {                                                         // ---- next ray of the request
+                ShadowRay sr = light_shadow_ray<C>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
+                r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
+                rays++; flying = true; occluded = false;
+                for (uint32_t i = 0; i < sc.n_unbounded && !occluded; i++) {
+                    uint32_t code = sc.obj_code[sc.unbounded[i]]; prims++;
+                    occluded = fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
+                }
+                if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
+                    for (uint32_t i = 0; i < sc.n_media && !occluded; i++) {
+                        rt_medium md = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; prims++;
+                        occluded = fast_object_solid<C>(sc, md.boundary_type, md.boundary_index, r, kMin, kMax);      // ConstantDensityMedium.cs:77
+                    }
+                }
+                if (!occluded && sc.n_nodes) { invD = splat(1.0f) / r.d; cur = 0; sp = 0; }
+            }
+        }
+        if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
+            if (!__any(flying || p_next < n)) break;
+            continue;                                                           // (rays decided without the tree: account, draw again)
+        }
+        for (;;) {
+            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
+            if (pend != TRAV_DONE) {
+                prims++;
+                if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) { occluded = true; cur = TRAV_DONE; pend = TRAV_DONE; }
+                else leaf_advance(tree, cur, pend, sp);
+            }
+            const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
+            const int n_busy = __popcll(__ballot(busy));
+            if (n_busy == 0) break;
+            if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && (flying || p_next < n))) >= REFILL_MIN_TAKERS) break;
+        }
+    }
+    stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
+}
+
 // UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — passes of the batch are added in pass order.
 __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum, uint32_t n_passes) {
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < rd.n_pixels; pix += gridDim.x * BLOCK) {
@@ -566,6 +684,7 @@ struct KernelSet {
     void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
     // LdsTree forms (null when the variant has none)
     void (*closest_persistent)(SceneDev, RenderDev, uint32_t);     // heavy-tailed scenes (see k_closest_persistent)
+    void (*shadow_persistent)(SceneDev, RenderDev, uint32_t);
     void (*closest_lds)(SceneDev, RenderDev, uint32_t);
     void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
@@ -573,7 +692,7 @@ struct KernelSet {
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
-                k_closest_persistent<C, false>, nullptr, nullptr, nullptr, nullptr};
+                k_closest_persistent<C, false>, k_shadow_persistent<C, false>, nullptr, nullptr, nullptr, nullptr};
     if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }

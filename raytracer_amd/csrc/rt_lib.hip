@@ -77,6 +77,7 @@ struct rt_scene {
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
     DevBuf lds_image;
     uint32_t n_objects = 0, n_lights = 0;
@@ -361,6 +362,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 894 Msamples/s with
     // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
+    { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
     { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && nodes.size() * sizeof(Node) > (64u << 20)); }
     *out = s.release();
     return RT_OK;
@@ -563,6 +565,9 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
     const size_t lds = stack_bytes(s);
+    // A request with many rays (64 lights: 64 traversals, each ending at its own time) is where a lane should not wait for its
+    // wave: 100 k spheres + 64 lights 766 -> 728 ms per batch; with 2-4 rays per request the refill rounds cost more than they save.
+    const bool shadow_persistent = s->persistent_shadow >= 0 ? s->persistent_shadow != 0 : (uint64_t)rd.light_samples * s->n_lights >= 32;
     { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
@@ -571,7 +576,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (s->use_lds) hipLaunchKernelGGL(ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
-          else hipLaunchKernelGGL(ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+          else hipLaunchKernelGGL(shadow_persistent ? ks->shadow_persistent : ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on
     if (r->batches_enqueued > 0 && r->n_slots > 1) HIP_TRY(hipStreamWaitEvent(st, r->ev_acc[(si + r->n_slots - 1) % r->n_slots], 0));

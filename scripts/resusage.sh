@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel VGPR / SGPR / occupancy / scratch of the gfx950 build
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -c raytracer_amd/csrc/rt_lib.hip -o /tmp/rt_lib_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc $RU_EXTRA -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -c raytracer_amd/csrc/rt_lib.hip -o /tmp/rt_lib_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re,subprocess
 cur={}
 rows=[]
