@@ -1,5 +1,5 @@
 # Builds the gfx950 library (product) and the CPU oracle (test infrastructure).
-#   make            -> raytracer_amd/librt_hip.so + oracle/liboracle.so
+#   make            -> raytracer_amd/librt_hip.so + oracle/liboracle.so + tools/rtbench
 # hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off on both sides: the reference's JIT never
 # fuses a*b+c, and the bit-exact parity of K / hit ids depends on one rounding per operator.
 HIPCC    ?= /opt/rocm/bin/hipcc
@@ -11,8 +11,9 @@ ORCFLAGS ?= -O2 -std=c++17 -march=x86-64-v3 -ffp-contract=off -fno-fast-math -fP
 CSRC := raytracer_amd/csrc
 LIB  := raytracer_amd/librt_hip.so
 ORC  := oracle/liboracle.so
+BENCH := tools/rtbench
 
-all: $(LIB) $(ORC)
+all: $(LIB) $(ORC) $(BENCH)
 
 $(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h include/rt_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_lib.hip $(CSRC)/rt_bvh.cpp
@@ -20,7 +21,11 @@ $(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_b
 $(ORC): oracle/oracle.cpp include/rt_hip.h
 	$(CXX) $(ORCFLAGS) -shared -o $@ oracle/oracle.cpp
 
+# the C-ABI driver: plain g++, links the library and nothing else (no HIP headers, no Python)
+$(BENCH): tools/rtbench.cpp include/rt_hip.h $(LIB)
+	$(CXX) -O2 -std=c++17 -Wall -o $@ tools/rtbench.cpp -Lraytracer_amd -lrt_hip -Wl,-rpath,'$$ORIGIN/../raytracer_amd'
+
 clean:
-	rm -f $(LIB) $(ORC)
+	rm -f $(LIB) $(ORC) $(BENCH)
 
 .PHONY: all clean

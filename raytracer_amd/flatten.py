@@ -38,6 +38,28 @@ class FlatScene:
         self.n_objects, self.n_materials, self.n_lights = n_objects, n_materials, n_lights
 
 
+# rt_scene_desc's tables, in order (the .rtscene file and tools/rtbench.cpp follow it)
+_TABLES = ("objects", "spheres", "quads", "triangles", "infinite_planes", "xy_planes", "xz_planes", "yz_planes", "disks", "boxes", "capsules",
+           "cylinders", "media", "materials", "textures", "lights")
+
+
+def save_rtscene(flat: "FlatScene", path: str) -> None:
+    """Write the flattened tables to a file a host in any language can hand to rt_scene_create (SURVEY §8d "scenes dumped to
+    .rtscene"): "RTSCENE1", u32 abi_version, rt_camera, rt_skybox, then per table { u32 count, u32 element size, bytes }."""
+    import ctypes as C
+    d = flat.desc
+    with open(path, "wb") as f:
+        f.write(b"RTSCENE1")
+        f.write(np.uint32(d.abi_version).tobytes())
+        f.write(bytes(d.camera)); f.write(bytes(d.skybox))
+        for name in _TABLES:
+            n = int(getattr(d, "n_" + name)); ptr = getattr(d, name)
+            elem = C.sizeof(ptr._type_)
+            f.write(np.array([n, elem], np.uint32).tobytes())
+            if n:
+                f.write(C.string_at(ptr, n * elem))
+
+
 class DeviceSceneBuilder:
     def __init__(self):
         self._prims: Dict[int, List[np.ndarray]] = {t: [] for t in _PRIM_FLOATS}

@@ -140,6 +140,7 @@ class RenderJob:
         self._started = threading.Lock()
         self._cancel = threading.Event()
         self._passes_done = 0            # this rank's passes
+        self.PassesSoFar = 0             # advanced after every rt_render_passes call (what a progress display reads while the task runs)
         self.passes_per_call = 0         # 0 = all of this rank's passes in one rt_render_passes call
 
     # ---- RenderJob.cs:708-723 -----------------------------------------------------------------------------------
@@ -184,6 +185,7 @@ class RenderJob:
             m = min(chunk, n_passes - done)
             capi.check(self._lib.rt_render_passes(self.handle, first_pass + done * stride, m, stride))
             done += m
+            self.PassesSoFar += m
         self._passes_done += n_passes
 
     def ReduceToRoot(self):

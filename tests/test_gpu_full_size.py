@@ -156,3 +156,39 @@ def test_config5_hundred_thousand_spheres_64_lights():
     j = rt.RenderJob(sc, opt_s, device_scene=dev); j.Wait(); g, _ = j.ReadAccum(); j.Dispose()
     ref, _ = orc.render(opt_s, threads=16)
     assert _image_close(g, ref) > 0.95
+
+
+def test_check1_two_million_rays_night_spheres():
+    """SURVEY §8d check 1 at its stated size: >= 1 M primary + 1 M secondary rays from the oracle on config 2's scene."""
+    sc = bs.Testing(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    rs = np.random.default_rng(2_000_000)
+    o1, d1 = helpers.camera_rays(sc, 1920, 1080, 1_000_000, rs)
+    o2, d2 = helpers.secondary_rays(flat, 1_000_000, rs)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    g = dev.TraceClosest(o, d, 0.001, np.inf, seed=3)
+    r = orc.trace_closest(o, d, 0.001, np.inf, seed=3)
+    excluded = helpers.assert_closest_parity(g, r)
+    assert len(excluded) <= 20                                                    # "expected ~ 0"
+    assert (r["object"] != NO_HIT).sum() > 500_000
+
+
+@pytest.mark.parametrize("name,w,h,passes,depth", [("Testing", 160, 90, 32, 10), ("Demo", 160, 90, 32, 8), ("CornellBox", 96, 96, 32, 32)])
+def test_check2_rmse_against_the_oracles_noise_floor(name, w, h, passes, depth):
+    """SURVEY §8d check 2: with DIFFERENT seeds on the two sides (so nothing is compared path by path), the device image's RMSE
+    against an oracle image is at most 1.5 x the RMSE between two independent oracle images at the same spp, per channel, and
+    the channel means agree within 0.5 % (+ the standard error of the mean at this spp)."""
+    sc = helpers.small_scenes()[name](); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    def opt(seed): return RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=2, Seed=seed)
+    job = rt.RenderJob(sc, opt(101), device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); job.Dispose()
+    ref_a, _ = orc.render(opt(202), threads=16)
+    ref_b, _ = orc.render(opt(303), threads=16)
+    got, ref_a, ref_b = got / passes, ref_a / passes, ref_b / passes
+    fin = np.isfinite(got).all(axis=2) & np.isfinite(ref_a).all(axis=2) & np.isfinite(ref_b).all(axis=2)
+    assert fin.mean() > 0.999
+    for c in range(3):
+        floor = np.sqrt(np.mean((ref_a[fin][:, c] - ref_b[fin][:, c]) ** 2))
+        rmse = np.sqrt(np.mean((got[fin][:, c] - ref_a[fin][:, c]) ** 2))
+        assert rmse <= 1.5 * floor + 1e-6, f"channel {c}: RMSE {rmse} vs noise floor {floor}"
+        sem = floor / np.sqrt(fin.sum())
+        m_ref, m_got = ref_a[fin][:, c].mean(), got[fin][:, c].mean()
+        assert abs(m_got - m_ref) <= 0.005 * abs(m_ref) + 4 * sem + 1e-6, f"channel {c}: mean {m_got} vs {m_ref}"
