@@ -15,8 +15,8 @@ BENCH := tools/rtbench
 
 all: $(LIB) $(ORC) $(BENCH)
 
-$(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h include/rt_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_lib.hip $(CSRC)/rt_bvh.cpp
+$(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h $(CSRC)/rt_lbvh.hip include/rt_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_lib.hip $(CSRC)/rt_lbvh.hip $(CSRC)/rt_bvh.cpp
 
 $(ORC): oracle/oracle.cpp include/rt_hip.h
 	$(CXX) $(ORCFLAGS) -shared -o $@ oracle/oracle.cpp

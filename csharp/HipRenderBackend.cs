@@ -87,6 +87,14 @@ internal static unsafe class RtHip
 		public uint NLights;         public Light*         Lights;
 	}
 
+	/// <summary>rt_scene_info: what BvhTree's construction log lines report (Acceleration/BvhTree.cs:29-41), plus the kernel variant and tree placement</summary>
+	[StructLayout(LayoutKind.Sequential)]
+	public unsafe struct SceneInfo
+	{
+		public uint NObjects, NUnbounded, NNodes, BvhDepth, TreeInLds, LdsImageBytes, BuiltOnDevice, Reserved;
+		public fixed byte Variant[16];
+	}
+
 	[StructLayout(LayoutKind.Sequential)]
 	public struct RenderOpts
 	{
@@ -111,6 +119,7 @@ internal static unsafe class RtHip
 	[DllImport(Lib)] public static extern int    rt_device_count(out int n);
 	[DllImport(Lib)] public static extern int    rt_scene_create(SceneDesc* desc, int device, out IntPtr scene);
 	[DllImport(Lib)] public static extern int    rt_scene_destroy(IntPtr scene);
+	[DllImport(Lib)] public static extern int    rt_scene_get_info(IntPtr scene, out SceneInfo info);
 	[DllImport(Lib)] public static extern int    rt_render_create(IntPtr scene, RenderOpts* opts, out IntPtr render);
 	[DllImport(Lib)] public static extern int    rt_render_destroy(IntPtr render);
 	[DllImport(Lib)] public static extern int    rt_render_passes(IntPtr render, ulong firstPass, uint nPasses, uint passStride);

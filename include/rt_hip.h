@@ -344,6 +344,8 @@ typedef struct rt_scene_info {
     uint32_t n_nodes, bvh_depth;      /* inner nodes (64 B each) and deepest inner level */
     uint32_t tree_in_lds;             /* 1: the tree and sphere table are copied into each workgroup's LDS */
     uint32_t lds_image_bytes;
+    uint32_t built_on_device;         /* 1: Morton-order build on the GPU (>= 256 k bounded objects), 0: binned SAH on the host */
+    uint32_t reserved;
     char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
 } rt_scene_info;
 int rt_scene_get_info(rt_scene* scene, rt_scene_info* out);

@@ -13,6 +13,7 @@
 
 #include "../../include/rt_hip.h"
 #include "rt_bvh.h"
+namespace rtlbvh { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, std::string& err); }
 #include "rt_kernels.h"
 
 using namespace rtd;
@@ -77,6 +78,7 @@ struct rt_scene {
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    bool device_build = false;       // the tree was built by rt_lbvh.hip
     int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
     DevBuf lds_image;
@@ -234,7 +236,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rtbvh::Box b; for (int a = 0; a < 3; a++) { b.mn[a] = o.aabb_min[a]; b.mx[a] = o.aabb_max[a]; }
         boxes.push_back(b); box_obj.push_back(i);
     }
-    rtbvh::BuildResult bvh = rtbvh::build(boxes, box_obj);
+    // Builder: binned SAH on the host (rt_bvh.cpp, subtrees on all host threads: 5 M triangles in well under a second), or, with
+    // RT_HIP_BVH=device, Morton order + Karras links + bottom-up refit on the device (rt_lbvh.hip): tens of milliseconds, but rays
+    // then do 15 % more box tests (C4: 898 -> 711 Msamples/s), so it is for scenes rebuilt more often than they are rendered.
+    bool device_build = false;
+    if (const char* e = getenv("RT_HIP_BVH")) device_build = !strcmp(e, "device") && boxes.size() >= 2;
+    rtbvh::BuildResult bvh;
+    if (!device_build) bvh = rtbvh::build(boxes, box_obj);
 
     // what the scene contains -> the most specific kernel variant that covers it (RT_HIP_VARIANT=generic forces the general one; test knob)
     uint32_t m_prims = 0, m_mats = 0, m_texs = 0, m_lights = 0;
@@ -313,7 +321,16 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     static_assert(sizeof(Node) == sizeof(rtbvh::HostNode), "node layouts must agree");
     if (!nodes.empty()) memcpy(nodes.data(), bvh.nodes.data(), nodes.size() * sizeof(Node));
 #define UP(buf, vec) if ((rc = upload(s->buf, vec))) return rc
-    UP(nodes, nodes); UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
+    size_t n_nodes = nodes.size();
+    if (device_build) {
+        n_nodes = boxes.size() - 1;
+        HIP_TRY(s->nodes.alloc(n_nodes * sizeof(Node)));
+        std::string err;
+        int brc = rtlbvh::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, err);
+        if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "device BVH build: %s", err.c_str());
+    } else UP(nodes, nodes);
+    s->device_build = device_build;
+    UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
     UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis[0], axis[0]); UP(axis[1], axis[1]); UP(axis[2], axis[2]);
     UP(disks, disks); UP(boxes, bxs); UP(capsules, caps); UP(cylinders, cyls);
     std::vector<rt_medium> mrec(d->media, d->media + d->n_media);
@@ -323,7 +340,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     UP(media_rec, mrec); UP(materials, mats); UP(textures, texs); UP(lights, lts);
 #undef UP
     SceneDev& sd = s->dev;
-    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)nodes.size();
+    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)n_nodes;
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>(); sd.n_objects = d->n_objects;
     sd.unbounded = s->unbounded.as<uint32_t>(); sd.n_unbounded = (uint32_t)unbounded.size();
     sd.media = s->media.as<uint32_t>(); sd.n_media = (uint32_t)media.size();
@@ -363,7 +380,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 894 Msamples/s with
     // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
     { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
-    { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && nodes.size() * sizeof(Node) > (64u << 20)); }
+    { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && n_nodes * sizeof(Node) > (64u << 20)); }
     *out = s.release();
     return RT_OK;
 }
@@ -373,6 +390,7 @@ int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
     memset(out, 0, sizeof(*out));
     out->n_objects = s->n_objects; out->n_unbounded = s->dev.n_unbounded; out->n_nodes = s->dev.n_nodes; out->bvh_depth = s->bvh_depth;
     out->tree_in_lds = s->use_lds ? 1u : 0u; out->lds_image_bytes = s->dev.lds_image_bytes;
+    out->built_on_device = s->device_build ? 1u : 0u;
     strncpy(out->variant, s->ks->name, sizeof(out->variant) - 1);
     return RT_OK;
 }

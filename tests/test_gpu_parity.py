@@ -188,3 +188,26 @@ def test_debug_visualisations_match_the_oracle(pairs, name, vis):
     assert n == 3 and np.isfinite(got).all()
     close = (np.abs(got - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2) + 1e-5).all(axis=2).mean()
     assert close > 0.985, f"{VIS_NAMES[vis]} on {name}: only {close:.4f} of pixels match"
+
+
+@pytest.mark.parametrize("name", ["Testing", "MiniMesh", "MiniManyLights", "Zoo", "RgbSpheres"])
+def test_device_built_tree_gives_the_same_hits(pairs, name, monkeypatch):
+    """RT_HIP_BVH=device: Morton-order build on the GPU (rt_lbvh.hip).  Another tree, the same closest hits and any-hit answers."""
+    sc, flat, dev_host, orc = pairs(name)
+    monkeypatch.setenv("RT_HIP_BVH", "device")
+    dev = rt.DeviceScene(flat)
+    monkeypatch.delenv("RT_HIP_BVH")
+    assert dev.Info()["built_on_device"] and not dev_host.Info()["built_on_device"]
+    assert dev.Info()["n_nodes"] == dev_host.Info()["n_nodes"]
+    o, d = ray_set(sc, flat, 50_000, 31)
+    g = dev.TraceClosest(o, d, 0.001, np.inf, seed=5)
+    helpers.assert_closest_parity(g, orc.trace_closest(o, d, 0.001, np.inf, seed=5))
+    kmin = np.full(len(o), 0.01, np.float32); kmax = np.random.default_rng(6).uniform(0.1, 30.0, len(o)).astype(np.float32)
+    assert np.array_equal(dev.TraceAny(o, d, kmin, kmax), orc.trace_any(o, d, kmin, kmax))
+    opt = RenderOptions(RenderWidth=64, RenderHeight=36, Passes=3, MaxBounceDepth=6, Seed=9)
+    a = rt.RenderJob(sc, opt, device_scene=dev); a.Wait()
+    b = rt.RenderJob(sc, opt, device_scene=dev_host); b.Wait()
+    ga, gb = a.ReadAccum()[0], b.ReadAccum()[0]
+    fin = np.isfinite(ga).all(axis=2) & np.isfinite(gb).all(axis=2)
+    assert (np.abs(ga - gb)[fin] <= 1e-4 * np.maximum(np.abs(gb)[fin], 1e-3)).all(axis=1).mean() > 0.995       # only near-ties may pick another object
+    a.Dispose(); b.Dispose(); dev.Dispose()
