@@ -149,7 +149,11 @@ typedef struct rt_object {
  * ------------------------------------------------------------------------------------------ */
 typedef enum rt_texture_type {
     RT_TEX_SOLID  = 0,               /* SolidColourTexture.cs:14 : f[0..2] = colour */
-    RT_TEX_MARBLE = 1                /* MarbleTexture.cs:18-48  : f[0]=Scale f[1]=NoiseScale f[2]=NoiseStrength f[3]=DropoffPower */
+    RT_TEX_MARBLE = 1,               /* MarbleTexture.cs:18-48  : f[0]=Scale f[1]=NoiseScale f[2]=NoiseStrength f[3]=DropoffPower */
+    RT_TEX_GREYSCALE_PERLIN = 2      /* GreyscaleNoiseTexture.cs:20 whose Module is a SharpNoise Perlin (any other Module is opaque: rejected):
+                                        f[0]=Frequency f[1]=Lacunarity f[2]=Persistence f[3]=OctaveCount f[4]=Seed (integers as floats);
+                                        colour = (v, v, v), v = the module's value at WorldPoint, NOT clamped (GreyscaleNoiseTexture.cs:20).
+                                        Same stand-in gradient noise as MarbleTexture: parity unpinned (SharpNoise is not in the tree) */
 } rt_texture_type;
 
 typedef struct rt_texture {

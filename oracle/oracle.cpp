@@ -703,15 +703,18 @@ static float coherent_noise(float x, float y, float z, int32_t seed) {
     float iy1 = lerpf(ix0, ix1, ys);
     return lerpf(iy0, iy1, zs);
 }
-static float marble_noise(float x, float y, float z) {
-    float value = 0.0f, persistence = 1.0f;
-    for (int o = 0; o < 5; o++) {
-        value = value + (coherent_noise(x, y, z, o) * persistence);
-        x = x * 3.0f; y = y * 3.0f; z = z * 3.0f;
-        persistence = persistence * 0.5f;
+// libnoise's Perlin::GetValue (SharpNoise.Modules.Perlin): octaves of coherent noise, seed + octave each
+static float perlin_noise(float x, float y, float z, float frequency, float lacunarity, float persistence, int octaves, int32_t seed) {
+    float value = 0.0f, amplitude = 1.0f;
+    x = x * frequency; y = y * frequency; z = z * frequency;
+    for (int o = 0; o < octaves; o++) {
+        value = value + (coherent_noise(x, y, z, seed + o) * amplitude);
+        x = x * lacunarity; y = y * lacunarity; z = z * lacunarity;
+        amplitude = amplitude * persistence;
     }
     return value;
 }
+static float marble_noise(float x, float y, float z) { return perlin_noise(x, y, z, 1.0f, 3.0f, 0.5f, 5, 0); }      // MarbleTexture.cs:11-17
 
 struct SceneData;
 static Colour TextureColour(const SceneData& sc, uint32_t tex, const HitRecord& hit);
@@ -791,6 +794,10 @@ static bool AnyIntersectionFast(const SceneData& sc, const Ray& ray, float kMin,
 static Colour TextureColour(const SceneData& sc, uint32_t tex, const HitRecord& hit) {
     const rt_texture& t = sc.textures[tex];
     if (t.type == RT_TEX_SOLID) return col(t.f);                                                      // SolidColourTexture.cs:14
+    if (t.type == RT_TEX_GREYSCALE_PERLIN) {                                                          // GreyscaleNoiseTexture.cs:20 (PARITY UNPINNED, as marble)
+        float v = perlin_noise(hit.WorldPoint.x, hit.WorldPoint.y, hit.WorldPoint.z, t.f[0], t.f[1], t.f[2], (int)t.f[3], (int32_t)t.f[4]);
+        return Colour{v, v, v};
+    }
     // MarbleTexture.cs:38-48
     float Scale = t.f[0], NoiseScale = t.f[1], NoiseStrength = t.f[2], DropoffPower = t.f[3];
     float x = hit.WorldPoint.x / Scale, y = hit.WorldPoint.y / Scale, z = hit.WorldPoint.z / Scale;

@@ -15,7 +15,7 @@ RT_DEPTH_HIST_SIZE = 64
 # rt_hittable_type
 (HIT_SPHERE, HIT_QUAD, HIT_TRIANGLE, HIT_INFINITE_PLANE, HIT_XY_PLANE, HIT_XZ_PLANE, HIT_YZ_PLANE, HIT_DISK, HIT_BOX, HIT_CAPSULE,
  HIT_CYLINDER, HIT_MEDIUM) = range(12)
-TEX_SOLID, TEX_MARBLE = 0, 1
+TEX_SOLID, TEX_MARBLE, TEX_GREYSCALE_PERLIN = 0, 1, 2
 MAT_STANDARD, MAT_REFRACTIVE, MAT_EMISSIVE_REFRACTIVE, MAT_PHONG, MAT_VOLUMETRIC = range(5)
 MAT_FLAG_ALTERNATE_REFRACTION, MAT_FLAG_DIRECT_EMISSION = 1, 2
 LIGHT_POINT, LIGHT_DIFFUSE_SPHERE, LIGHT_DIFFUSE_SHAPED = range(3)

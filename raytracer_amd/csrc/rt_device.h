@@ -802,20 +802,27 @@ RT_FN float coherent_noise(float x, float y, float z, int32_t seed) {
     float iy1 = lerpf(ix0, ix1, ys);
     return lerpf(iy0, iy1, zs);
 }
-RT_FN float marble_noise(float x, float y, float z) {
-    float value = 0.0f, persistence = 1.0f;
-    for (int o = 0; o < 5; o++) {
-        value = value + (coherent_noise(x, y, z, o) * persistence);
-        x = x * 3.0f; y = y * 3.0f; z = z * 3.0f;
-        persistence = persistence * 0.5f;
+// libnoise's Perlin::GetValue: octaves of coherent noise, seed + octave each, frequency x lacunarity, amplitude x persistence
+RT_FN float perlin_noise(float x, float y, float z, float frequency, float lacunarity, float persistence, int octaves, int32_t seed) {
+    float value = 0.0f, amplitude = 1.0f;
+    x = x * frequency; y = y * frequency; z = z * frequency;
+    for (int o = 0; o < octaves; o++) {
+        value = value + (coherent_noise(x, y, z, seed + o) * amplitude);
+        x = x * lacunarity; y = y * lacunarity; z = z * lacunarity;
+        amplitude = amplitude * persistence;
     }
     return value;
 }
+RT_FN float marble_noise(float x, float y, float z) { return perlin_noise(x, y, z, 1.0f, 3.0f, 0.5f, 5, 0); }      // MarbleTexture.cs:11-17
 
 template <class C>
 RT_FN col3 texture_colour(const SceneDev& sc, uint32_t tex, f3 wp) {
     const rt_texture* t = sc.textures + tex;
-    if (!RT_HAS_TEX(C, RT_TEX_MARBLE) || t->type == RT_TEX_SOLID) return mkc(t->f[0], t->f[1], t->f[2]);                 // SolidColourTexture.cs:14
+    if (!(RT_HAS_TEX(C, RT_TEX_MARBLE) || RT_HAS_TEX(C, RT_TEX_GREYSCALE_PERLIN)) || t->type == RT_TEX_SOLID) return mkc(t->f[0], t->f[1], t->f[2]);   // SolidColourTexture.cs:14
+    if (RT_HAS_TEX(C, RT_TEX_GREYSCALE_PERLIN) && t->type == RT_TEX_GREYSCALE_PERLIN) {                                  // GreyscaleNoiseTexture.cs:20
+        float v = perlin_noise(wp.x, wp.y, wp.z, t->f[0], t->f[1], t->f[2], (int)t->f[3], (int32_t)t->f[4]);
+        return mkc(v, v, v);
+    }
     float scale = t->f[0], noiseScale = t->f[1], noiseStrength = t->f[2], dropoff = t->f[3];   // MarbleTexture.cs:38-48
     float x = wp.x / scale, y = wp.y / scale, z = wp.z / scale;
     float tt = x + y + z;

@@ -672,7 +672,7 @@ using CfgMesh    = Cfg<pbit(RT_HIT_TRIANGLE) | pbit(RT_HIT_INFINITE_PLANE), pbit
 using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_PLANE) | pbit(RT_HIT_XZ_PLANE) | pbit(RT_HIT_YZ_PLANE) | pbit(RT_HIT_QUAD),
                        pbit(RT_MAT_STANDARD) | pbit(RT_MAT_REFRACTIVE) | pbit(RT_MAT_EMISSIVE_REFRACTIVE), pbit(RT_TEX_SOLID),
                        pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
-using CfgAll     = Cfg<(1u << RT_HIT_TYPE_COUNT) - 1, 0x1Fu, 0x3u, 0x7u>;
+using CfgAll     = Cfg<(1u << RT_HIT_TYPE_COUNT) - 1, 0x1Fu, 0x7u, 0x7u>;
 
 struct KernelSet {
     const char* name;

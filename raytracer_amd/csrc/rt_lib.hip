@@ -206,7 +206,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
 #undef NEED
     if (d->skybox.type > RT_SKY_SINGLE_COLOUR) return fail(RT_ERR_UNSUPPORTED, "unknown skybox type %u (user-defined SkyBoxes are rejected)", d->skybox.type);
     for (uint32_t i = 0; i < d->n_textures; i++)
-        if (d->textures[i].type > RT_TEX_MARBLE) return fail(RT_ERR_UNSUPPORTED, "texture %u: unknown type %u (GreyscaleNoise/CustomFunction textures are rejected)", i, d->textures[i].type);
+    {
+        if (d->textures[i].type > RT_TEX_GREYSCALE_PERLIN) return fail(RT_ERR_UNSUPPORTED, "texture %u: unknown type %u (CustomFunction textures and noise modules other than Perlin are rejected)", i, d->textures[i].type);
+        if (d->textures[i].type == RT_TEX_GREYSCALE_PERLIN) {
+            const float oc = d->textures[i].f[3], sd = d->textures[i].f[4];
+            if (!(oc >= 1.0f && oc <= 30.0f) || oc != std::floor(oc)) return fail(RT_ERR_INVALID_ARG, "texture %u: Perlin OctaveCount %g outside 1..30", i, (double)oc);     // SharpNoise's Perlin.MaxOctaves
+            if (!(std::fabs(sd) <= 16777216.0f) || sd != std::floor(sd)) return fail(RT_ERR_INVALID_ARG, "texture %u: Perlin Seed %g is not an integer a float holds", i, (double)sd);
+        }
+    }
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rt_material& m = d->materials[i];
         if (m.type > RT_MAT_VOLUMETRIC) return fail(RT_ERR_UNSUPPORTED, "material %u: unknown type %u (user-defined Materials are rejected)", i, m.type);

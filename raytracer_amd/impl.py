@@ -49,11 +49,26 @@ class MarbleTexture(Texture):
         return b.add_texture(capi.TEX_MARBLE, [self.Scale, self.NoiseScale, self.NoiseStrength, self.DropoffPower])
 
 
+class Perlin:
+    """SharpNoise.Modules.Perlin with its defaults (Frequency 1, Lacunarity 2, Persistence .5, OctaveCount 6, Seed 0).  Quality is
+    not modelled: the stand-in gradient noise interpolates linearly (NoiseQuality.Fast), as MarbleTexture's does."""
+
+    def __init__(self, Frequency=1.0, Lacunarity=2.0, Persistence=0.5, OctaveCount=6, Seed=0):
+        self.Frequency, self.Lacunarity, self.Persistence = f32(Frequency), f32(Lacunarity), f32(Persistence)
+        self.OctaveCount, self.Seed = int(OctaveCount), int(Seed)
+
+
 class GreyscaleNoiseTexture(Texture):
-    """GreyscaleNoiseTexture.cs — wraps an arbitrary SharpNoise Module: opaque, rejected (inherits Texture.flatten)."""
+    """GreyscaleNoiseTexture.cs:9-20.  A Perlin module runs on the device; any other SharpNoise Module is opaque and rejected."""
 
     def __init__(self, module=None):
         self.Module = module
+
+    def flatten(self, b):
+        if not isinstance(self.Module, Perlin):
+            raise NotSupportedError(f"GreyscaleNoiseTexture over {type(self.Module).__name__}: only a Perlin module can run on the device")
+        m = self.Module
+        return b.add_texture(capi.TEX_GREYSCALE_PERLIN, [m.Frequency, m.Lacunarity, m.Persistence, f32(m.OctaveCount), f32(m.Seed)])
 
 
 class CustomFunctionTexture(Texture):

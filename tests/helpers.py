@@ -19,8 +19,22 @@ def small_scenes():
         "Zoo": zoo_scene,
         "MiniMesh": lambda: bs.TriangleMesh(grid=24),
         "MiniManyLights": lambda: bs.ManySpheresManyLights(n_spheres=2000, n_lights=9),
+        "Noise": noise_scene,
         "Empty": empty_scene,
     }
+
+
+def noise_scene():
+    """GreyscaleNoiseTexture over a Perlin module (albedo and emission; the value is not clamped, so colours go negative as in the reference)."""
+    P = impl.Perlin
+    objs = [
+        SceneObject("a", impl.Sphere((-1.2, 1, 0), 1.0, Material=impl.StandardMaterial(impl.GreyscaleNoiseTexture(P(Frequency=2.0, OctaveCount=3, Seed=5)), 0.8))),
+        SceneObject("b", impl.Sphere((1.2, 1, 0), 1.0, Material=impl.StandardMaterial(Colour(.6, .6, .6), impl.GreyscaleNoiseTexture(P(Frequency=0.7, Lacunarity=3.0, Persistence=0.4, OctaveCount=2)), 1.0))),
+        SceneObject("c", impl.Sphere((0, 0.5, 1.8), 0.5, Material=impl.RefractiveMaterial(1.5, impl.GreyscaleNoiseTexture(P())))),
+        SceneObject("ground", impl.InfinitePlane((0, 0, 0), (0, 1, 0), Material=impl.StandardMaterial(impl.MarbleTexture(), 1.0))),
+    ]
+    lights = [impl.PointLight(Position=(0, 5, 3), AttenuationRadius=12)]
+    return Scene("Noise", Camera.Create((0, 2, 6), (0, 1, 0), (0, 1, 0), 45, 16 / 9, 0.0, 6.0), objs, lights, impl.DefaultSkyBox())
 
 
 def empty_scene():

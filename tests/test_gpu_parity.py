@@ -83,7 +83,7 @@ def test_edge_rays(pairs):
 
 @pytest.mark.parametrize("name,w,h,passes,depth,ls", [("Demo", 96, 54, 8, 8, 2), ("Testing", 96, 54, 8, 10, 2), ("CornellBox", 64, 64, 8, 32, 2),
                                                       ("Zoo", 64, 36, 8, 6, 1), ("MiniMesh", 64, 36, 4, 8, 2), ("MiniManyLights", 64, 36, 4, 10, 1),
-                                                      ("Empty", 16, 9, 2, 3, 1), ("RgbSpheres", 64, 36, 4, 10, 2)])
+                                                      ("Empty", 16, 9, 2, 3, 1), ("RgbSpheres", 64, 36, 4, 10, 2), ("Noise", 96, 54, 6, 8, 2)])
 def test_image_parity(pairs, name, w, h, passes, depth, ls):
     sc, flat, dev, orc = pairs(name)
     opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234)

@@ -67,7 +67,7 @@ class MyLight(Light):
     lambda: Scene("s", bs.Demo().Camera, [SceneObject("x", MyHittable())], [], impl.DefaultSkyBox()),
     lambda: Scene("s", bs.Demo().Camera, [SceneObject("x", impl.Sphere((0, 0, 0), 1, Material=MyMaterial()))], [], impl.DefaultSkyBox()),
     lambda: Scene("s", bs.Demo().Camera, [SceneObject("x", impl.Sphere((0, 0, 0), 1, Material=impl.StandardMaterial(impl.CustomFunctionTexture(lambda h: Colour.Red), 1.0)))], [], impl.DefaultSkyBox()),
-    lambda: Scene("s", bs.Demo().Camera, [SceneObject("x", impl.Sphere((0, 0, 0), 1, Material=impl.StandardMaterial(impl.GreyscaleNoiseTexture(), 1.0)))], [], impl.DefaultSkyBox()),
+    lambda: Scene("s", bs.Demo().Camera, [SceneObject("x", impl.Sphere((0, 0, 0), 1, Material=impl.StandardMaterial(impl.GreyscaleNoiseTexture(object()), 1.0)))], [], impl.DefaultSkyBox()),     # a Module that is not Perlin
     lambda: Scene("s", bs.Demo().Camera, [], [], MySky()),
     lambda: Scene("s", bs.Demo().Camera, [], [MyLight()], impl.DefaultSkyBox()),
     lambda: Scene("s", bs.Demo().Camera, [], [impl.PointLight(DistanceAttenuationFunc=lambda l, x: 1.0)], impl.DefaultSkyBox()),
@@ -75,6 +75,16 @@ class MyLight(Light):
 def test_user_defined_types_are_rejected_not_emulated(make):
     with pytest.raises(NotSupportedError):
         flatten_scene(make())
+
+
+def test_greyscale_noise_over_perlin_is_flattened():
+    from raytracer_amd import capi
+    sc = Scene("s", bs.Demo().Camera, [SceneObject("x", impl.Sphere((0, 0, 0), 1, Material=impl.StandardMaterial(impl.GreyscaleNoiseTexture(impl.Perlin(Frequency=2, OctaveCount=3, Seed=7)), 1.0)))],
+               [], impl.DefaultSkyBox())
+    flat = flatten_scene(sc)
+    t = [flat.desc.textures[i] for i in range(flat.desc.n_textures)]
+    noise = [x for x in t if x.type == capi.TEX_GREYSCALE_PERLIN]
+    assert len(noise) == 1 and list(noise[0].f[:5]) == [2.0, 2.0, 0.5, 3.0, 7.0]          # Frequency, Lacunarity (default 2), Persistence (.5), OctaveCount, Seed
 
 
 def test_render_options_validation_follows_the_reference_setters():
