@@ -60,6 +60,28 @@ RT_FN void stat_add(unsigned long long* stats, int slot, unsigned long long v) {
     v = wave_sum(v);
     if (lane_id() == 0 && v) atomicAdd(stats + slot, v);
 }
+// Three counters of a traversal kernel, one atomic per counter per WORKGROUP: every wave of every block adding to the same three
+// words costs 25 k same-address atomics per launch, which the L2 serialises (k_closest -4 %).  Every thread of the block must call it.
+template <int N>
+RT_FN void stat_add_block(unsigned long long* stats, const int (&slot)[N], const unsigned long long (&v)[N]) {
+    __shared__ unsigned long long red[N][16];
+    const uint32_t wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < N; i++) { const unsigned long long w = wave_sum(v[i]); if (lane_id() == 0) red[i][wave] = w; }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < n_waves; w++) t += red[threadIdx.x][w];
+        int sl = slot[0];
+#pragma unroll
+        for (int i = 1; i < N; i++) if ((int)threadIdx.x == i) sl = slot[i];
+        if (t) atomicAdd(stats + sl, t);
+    }
+}
+RT_FN void stat_add3_block(unsigned long long* stats, int s0, int s1, int s2, uint32_t v0, uint32_t v1, uint32_t v2) {
+    const int slot[3] = {s0, s1, s2}; const unsigned long long v[3] = {v0, v1, v2};
+    stat_add_block<3>(stats, slot, v);
+}
 
 RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
     uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
@@ -104,9 +126,7 @@ RT_FN auto make_tree(const SceneDev& sc) {
     }
 }
 
-// (A persistent-lane variant — every lane owning a strided series of rays, idle lanes refilled after a wave vote — was measured
-// here and lost to this plain grid-stride loop on MI355X: 17.1 vs 15.0 ms per 184 M rays.  The vote, the partial-wave fetch
-// phases and the extra registers cost more than the idle lanes they recover)
+// (Plain grid-stride loop: where rays cost about the same — Night Spheres — it beats k_closest_persistent below, 15.0 vs 17.1 ms per 184 M rays.)
 template <class C, bool LDS>
 __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
@@ -125,7 +145,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
         rays++; nodes += cnt.nodes; prims += cnt.prims;
     }
-    stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
+    stat_add3_block(rd.stats, ST_RAYS, ST_NODES, ST_PRIMS, rays, nodes, prims);
 }
 
 // Persistent-lane closest hit.  In scenes where the cost of a ray has a heavy tail (a bounce ray skimming a 5 M-triangle terrain
@@ -213,7 +233,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
             if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && j < n)) >= REFILL_MIN_TAKERS) break;
         }
     }
-    stat_add(rd.stats, ST_RAYS, rays); stat_add(rd.stats, ST_NODES, nodes); stat_add(rd.stats, ST_PRIMS, prims);
+    stat_add3_block(rd.stats, ST_RAYS, ST_NODES, ST_PRIMS, rays, nodes, prims);
 }
 
 // Output positions.  A same-address returning atomic is serviced about every 10 ns chip-wide, so a reservation per wave
@@ -412,9 +432,12 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
       }
       __syncthreads();       // wcnt / bases are reused by the next tile
     }
-    stat_add(rd.stats, ST_SKY, sky); stat_add(rd.stats, ST_LIMIT, limit); stat_add(rd.stats, ST_SCATTER, scat); stat_add(rd.stats, ST_SAMPLES, samples);
-    if (depth > 0) stat_add(rd.stats, ST_DEPTH0 + (int)min(depth - 1, (uint32_t)RT_DEPTH_HIST_SIZE - 1), hist_miss);
-    stat_add(rd.stats, ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1), limit);
+    {   // (RenderJob.cs:458: a miss at depth d ends a path of maxDepthReached d-1, the bounce limit one of depth d; a primary miss is not counted)
+        const int slot[6] = {ST_SKY, ST_LIMIT, ST_SCATTER, ST_SAMPLES, ST_DEPTH0 + (int)min(depth > 0 ? depth - 1 : 0u, (uint32_t)RT_DEPTH_HIST_SIZE - 1),
+                             ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1)};
+        const unsigned long long v[6] = {sky, limit, scat, samples, depth > 0 ? hist_miss : 0ull, limit};
+        stat_add_block<6>(rd.stats, slot, v);
+    }
 }
 
 // Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
@@ -482,7 +505,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k
         *tgt = t;
         nodes += cnt.nodes; prims += cnt.prims;
     }
-    stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
+    stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, nodes, prims);
 }
 
 // Persistent-lane k_shadow (same reasoning as k_closest_persistent).  A request's rays are traced one after the other by its
@@ -597,7 +620,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
             if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && (flying || p_next < n))) >= REFILL_MIN_TAKERS) break;
         }
     }
-    stat_add(rd.stats, ST_SHADOW_RAYS, rays); stat_add(rd.stats, ST_SH_NODES, nodes); stat_add(rd.stats, ST_SH_PRIMS, prims);
+    stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, nodes, prims);
 }
 
 // UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — passes of the batch are added in pass order.
