@@ -466,6 +466,22 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
 // -------------------------------------------------------------------------------------------------
 // Render job
 // -------------------------------------------------------------------------------------------------
+// everything a render handle owns (also the clean-up of a half-built one: rt_render_create fails through it)
+static void release_render(rt_render* r) {
+    for (int si = 0; si < MAX_SLOTS; si++) if (r->slots[si].stream) (void)hipStreamSynchronize(r->slots[si].stream);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    collect_stamps(r);
+    for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
+    for (int si = 0; si < MAX_SLOTS; si++) {
+        if (r->ev_acc[si]) (void)hipEventDestroy(r->ev_acc[si]);
+        if (si > 0 && r->slots[si].stream) (void)hipStreamDestroy(r->slots[si].stream);
+    }
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+struct RenderDeleter { void operator()(rt_render* r) const { release_render(r); } };
+
 int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (!s || !o || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_create: null argument");
     *out = nullptr;
@@ -482,7 +498,7 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (n_pixels > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
 
     DeviceGuard guard(s->device);
-    auto r = std::make_unique<rt_render>();
+    std::unique_ptr<rt_render, RenderDeleter> r(new rt_render());
     r->scene = s; r->opts = *o;
     // paths per batch: the alive paths fall to ~1 % by bounce 10, and a launch needs >> 0.5 M rays to fill 256 CUs, so batches are
     // big (128 M paths = 26 GB of state per slot): sized for 288 GB of HBM, not for a cache
@@ -558,16 +574,7 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
 int rt_render_destroy(rt_render* r) {
     if (!r) return RT_OK;
     DeviceGuard guard(r->scene->device);
-    for (int si = 0; si < r->n_slots; si++) if (r->slots[si].stream) (void)hipStreamSynchronize(r->slots[si].stream);
-    collect_stamps(r);
-    for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
-    for (int si = 0; si < r->n_slots; si++) {
-        if (r->ev_acc[si]) (void)hipEventDestroy(r->ev_acc[si]);
-        if (si > 0 && r->slots[si].stream) (void)hipStreamDestroy(r->slots[si].stream);
-    }
-    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
-    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
-    delete r;
+    release_render(r);
     return RT_OK;
 }
 
