@@ -24,6 +24,21 @@ def scene_table():
     return table
 
 
+def obj_scene(path, aspect):
+    """An imported model on a ground plane under the default sky, seen from a corner of its bounding box."""
+    import numpy as np
+    from . import impl, mesh_io
+    mesh = mesh_io.load_obj(path, Material=impl.StandardMaterial(core.Colour(0.7), 1.0))
+    pts = np.concatenate([mesh.v0, mesh.v1, mesh.v2])
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    centre, size = (lo + hi) / 2, float(np.linalg.norm(hi - lo)) or 1.0
+    eye = centre + np.array([0.9, 0.6, 1.2], np.float32) * size
+    cam = core.Camera.Create(tuple(eye), tuple(centre), (0, 1, 0), 40, aspect, 0.0, float(np.linalg.norm(eye - centre)))
+    ground = core.SceneObject("ground", impl.InfinitePlane((0, float(lo[1]), 0), (0, 1, 0), Material=impl.StandardMaterial(core.Colour(0.5), 0.9)))
+    light = impl.PointLight(Position=tuple(centre + np.array([0.5, 1.5, 0.8], np.float32) * size), AttenuationRadius=4 * size)
+    return core.Scene(path, cam, [ground], [light], impl.DefaultSkyBox(), BulkObjects=[mesh])
+
+
 VIS_NAMES = {k.rstrip("_"): v for k, v in vars(core.GraphicsDebugVisualisation).items() if not k.startswith("_") and isinstance(v, int)}
 
 
@@ -36,6 +51,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m raytracer_amd", description=__doc__.split("\n\n")[0])
     ap.add_argument("--list", action="store_true", help="list the scenes and exit")
     ap.add_argument("--scene", default="Demo")
+    ap.add_argument("--obj", default=None, help="render a Wavefront OBJ file (grey diffuse, a ground plane, one light, camera fitted) instead of a builtin scene")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--passes", type=int, default=100)
@@ -55,6 +71,9 @@ def main(argv=None):
         for name in table:
             print(name)
         return 0
+    if a.obj:
+        table = {"obj": lambda: obj_scene(a.obj, a.width / a.height)}
+        a.scene = "obj"
     match = [n for n in table if n.lower() == a.scene.lower()] or [n for n in table if a.scene.lower() in n.lower()]
     if len(match) != 1:
         print(f"scene {a.scene!r}: {'ambiguous: ' + ', '.join(match) if match else 'unknown'}; --list shows the names", file=sys.stderr)

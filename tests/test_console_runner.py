@@ -37,3 +37,12 @@ def test_runner_saves_the_job_image(tmp_path):
     job.Dispose()
     assert runner.main(["--scene", "Demo", "--width", "64", "--height", "36", "--passes", "1", "--vis", "Normals", "--out", str(out)]) == 0
     assert np.asarray(Image.open(out)).shape == (36, 64, 3)
+
+
+@pytest.mark.gpu
+def test_runner_renders_an_obj_file(tmp_path):
+    from PIL import Image
+    obj = tmp_path / "quad.obj"; obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    out = tmp_path / "o.png"
+    assert runner.main(["--obj", str(obj), "--width", "64", "--height", "36", "--passes", "2", "--out", str(out)]) == 0
+    assert np.asarray(Image.open(out)).shape == (36, 64, 3)
