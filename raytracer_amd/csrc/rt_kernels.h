@@ -149,14 +149,15 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
 }
 
 // Persistent-lane closest hit.  In scenes where the cost of a ray has a heavy tail (a bounce ray skimming a 5 M-triangle terrain
-// visits thousands of nodes, its 63 wave-mates a few dozen: 7 of 64 lanes busy on average) a lane must not wait for its wave.
-// Every lane owns a strided series of rays; the wave runs the same postponed-leaf loop, and after each leaf round it votes
-// (ballot + popcount): once fewer than REFILL_BELOW lanes are still traversing and at least REFILL_MIN_TAKERS idle lanes have
-// another ray to fetch, the idle lanes store their result and start their next ray.  All control flow is wave-uniform and the
-// result of a ray does not depend on the schedule.  (On Night Spheres, whose rays cost about the same, the votes and the
-// partial-wave fetch phases lose to the plain loop above: 17.1 vs 15.0 ms per 184 M rays; the host picks per scene.)
+// visits thousands of nodes, its 63 wave-mates a few dozen) a lane must not wait for its wave.  Every WAVE owns a contiguous run of
+// the queue; the wave runs the postponed-leaf loop, and after each leaf round it votes (ballot + popcount): once fewer than
+// REFILL_BELOW lanes are still traversing and at least REFILL_MIN_TAKERS are idle, the idle lanes store their results and take the
+// run's next rays — consecutive positions, so a refill is a coalesced load and the rays in flight stay neighbours.  All control
+// flow is wave-uniform and the result of a ray does not depend on the schedule.  Measured: 5 M triangles 790 -> 1014
+// Msamples/s; on Night Spheres, whose tree is in LDS, the refill rounds cost what the idle lanes recover (15.0 vs 15.2 ms), and
+// on the 10-object Cornell box they lose, so the host picks per scene.
 #ifndef RT_REFILL_BELOW
-#define RT_REFILL_BELOW 44
+#define RT_REFILL_BELOW 32
 #define RT_REFILL_MIN_TAKERS 8
 #endif
 #ifndef RT_CP_WAVES
@@ -171,8 +172,14 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     const uint32_t n = rd.qcount[depth];
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
     const float kMin = rd.k_min, kMax = rd.k_max;
-    const uint32_t stride = gridDim.x * TB;
-    uint32_t j = blockIdx.x * TB + threadIdx.x, my_j = 0;
+    // every wave owns a contiguous run of the queue and hands its next rays to whichever lanes are idle: a refill then loads
+    // consecutive positions (coalesced), and the rays a wave works on at one time stay neighbours in the image
+    const uint32_t n_waves = gridDim.x * (TB / 64), wave_id = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    const uint32_t per_wave = (n + n_waves - 1) / n_waves;
+    uint32_t next = min(n, wave_id * per_wave);                                  // wave-uniform cursor
+    const uint32_t end = min(n, next + per_wave);
+    const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
+    uint32_t my_j = 0;
     uint32_t rays = 0, nodes = 0, prims = 0;
     bool active = false;                 // this lane holds a ray (possibly finished and waiting for its store)
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
@@ -181,6 +188,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
     for (;;) {
         // ---- store / fetch for every lane that is not traversing
+        const unsigned long long idle = __ballot(cur == TRAV_DONE && pend == TRAV_DONE);
         if (cur == TRAV_DONE && pend == TRAV_DONE) {
             if (active) {
                 if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
@@ -199,10 +207,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 rd.hit[my_j] = make_float2(best.k, __uint_as_float(best.obj));
                 active = false;
             }
-            if (j < n) {
+            const uint32_t j = next + (uint32_t)__popcll(idle & lt_mask);
+            if (j < end) {
                 float4 a = g0[j], b = g1[j];
                 r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
-                my_j = j; j += stride; rays++;
+                my_j = j; rays++;
                 best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
                 sp = 0; active = true;
                 if (!ray_has_nan(r)) {
@@ -215,13 +224,15 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 }
             }
         }
+        next = min(end, next + (uint32_t)__popcll(idle));
         if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
-            if (!__any(active || j < n)) break;          // nothing traversing, nothing to store, nothing to fetch
+            if (!__any(active) && next >= end) break;     // nothing traversing, nothing to store, nothing to fetch
             continue;                                    // (rays that were finished at fetch time: store them, fetch again)
         }
         // ---- traverse until too few lanes are busy
         for (;;) {
-            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }
+            if constexpr (decltype(tree)::vote) { while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); } }
+            else while (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }
             if (pend != TRAV_DONE) {
                 uint32_t obj = (uint32_t)~pend; float k; prims++;
                 if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
             const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
             const int n_busy = __popcll(__ballot(busy));
             if (n_busy == 0) break;
-            if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && j < n)) >= REFILL_MIN_TAKERS) break;
+            if (n_busy < REFILL_BELOW && next < end && 64 - n_busy >= REFILL_MIN_TAKERS) break;
         }
     }
     stat_add3_block(rd.stats, ST_RAYS, ST_NODES, ST_PRIMS, rays, nodes, prims);
@@ -519,10 +530,15 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
     const uint32_t n_lights = sc.n_lights, per_request = rd.light_samples * n_lights;
-    const uint32_t stride = gridDim.x * TB;
+    // every wave owns a contiguous run of the request queue (as in k_closest_persistent)
+    const uint32_t n_waves = gridDim.x * (TB / 64), wave_id = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    const uint32_t per_wave = (n + n_waves - 1) / n_waves;
+    uint32_t next = min(n, wave_id * per_wave);
+    const uint32_t end = min(n, next + per_wave);
+    const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     uint32_t rays = 0, nodes = 0, prims = 0;
-    uint32_t p_next = blockIdx.x * TB + threadIdx.x, p = 0, q = 0, li = 0;      // q: index of the request's ray in flight, li = q mod n_lights
+    uint32_t p = 0, q = 0, li = 0;      // q: index of the request's ray in flight, li = q mod n_lights
     bool have = false, flying = false, occluded = false, second = false;       // second: the Phong material's unattenuated ray of the same light
     f3 wp = mk3(0, 0, 0), nrm = mk3(0, 0, 1), in = mk3(0, 0, 0);
     RngKey key = path_key(rd, 0);
@@ -534,6 +550,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
     int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
     for (;;) {
+        bool fetched = false;
         if (cur == TRAV_DONE && pend == TRAV_DONE) {
             if (flying) {                                                       // ---- account for the finished ray
                 flying = false;
@@ -573,8 +590,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
                     have = false;
                 }
             }
-            if (!have && p_next < n) {                                          // ---- next request
-                p = p_next; p_next += stride;
+            const uint32_t p_new = next + (uint32_t)__popcll(__ballot(!have) & lt_mask);      // (the idle lanes are the active ones here)
+            if (!have && p_new < end) {                                         // ---- next request
+                p = p_new; fetched = true;
                 float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
                 wp = mk3(h0.x, h0.y, h0.z); nrm = mk3(h0.w, h1.x, h1.y);
                 key = path_key(rd, __float_as_uint(h2.y));
@@ -603,8 +621,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
                 if (!occluded && sc.n_nodes) { invD = splat(1.0f) / r.d; cur = 0; sp = 0; }
             }
         }
+        next += (uint32_t)__popcll(__ballot(fetched));
         if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
-            if (!__any(flying || p_next < n)) break;
+            if (!__any(flying) && next >= end) break;
             continue;                                                           // (rays decided without the tree: account, draw again)
         }
         for (;;) {
@@ -617,7 +636,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_persi
             const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
             const int n_busy = __popcll(__ballot(busy));
             if (n_busy == 0) break;
-            if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && (flying || p_next < n))) >= REFILL_MIN_TAKERS) break;
+            if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && (flying || next < end))) >= REFILL_MIN_TAKERS) break;
         }
     }
     stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, nodes, prims);

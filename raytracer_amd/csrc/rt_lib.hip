@@ -384,7 +384,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                 HIP_TRY(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree_bytes_for(image_bytes, s->stack_depth, i < 2 ? LDS_BLOCK_CLOSEST : LDS_BLOCK_SHADOW)));
         }
     }
-    // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 894 Msamples/s with
+    // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 1014 Msamples/s with
     // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
     { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
     { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && n_nodes * sizeof(Node) > (64u << 20)); }
