@@ -363,7 +363,8 @@ int rt_render_destroy(rt_render* render);
  * device p mod G). Blocking. */
 int rt_render_passes(rt_render* render, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride);
 
-/* UpdateBuffers' resolve (RenderJob.cs:646-654): avg -> Clamp01 -> Sqrt -> (byte)(255*c); row 0 = top. */
+/* UpdateBuffers' resolve (RenderJob.cs:646-654): avg -> Clamp01 -> Sqrt -> (byte)(255*c); row 0 = top.
+ * Before the first pass the image is black, as the reference's freshly constructed Image<Rgb24> is. */
 int rt_render_read_rgb24(rt_render* render, uint8_t* dst /* width*height*3 */);
 /* rawColourBuffer / sampleCountBuffer (RenderJob.cs:669-672), image-row order (row 0 = top). */
 int rt_render_read_accum(rt_render* render, float* rgb_sum /* width*height*3 */, uint32_t* sample_count /* 1 value */);

@@ -211,3 +211,31 @@ def test_device_built_tree_gives_the_same_hits(pairs, name, monkeypatch):
     fin = np.isfinite(ga).all(axis=2) & np.isfinite(gb).all(axis=2)
     assert (np.abs(ga - gb)[fin] <= 1e-4 * np.maximum(np.abs(gb)[fin], 1e-3)).all(axis=1).mean() > 0.995       # only near-ties may pick another object
     a.Dispose(); b.Dispose(); dev.Dispose()
+
+
+def test_ragged_batches_tiny_images_and_zero_passes(pairs):
+    """Edge shapes of the pass loop: a last batch that is not full, a 1 x 1 image, a strided shard with a ragged tail, no passes at all."""
+    sc, flat, dev, orc = pairs("Demo")
+    def accum(w, h, passes, ppb, first=0, n=None, stride=1):
+        job = rt.RenderJob(sc, RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=6, Seed=42, PassesPerBatch=ppb), device_scene=dev)
+        job.RenderPasses(first, passes if n is None else n, stride)
+        a, cnt = job.ReadAccum(); st = job.UpdateStats(); job.Dispose()
+        return a, cnt, st
+    a, n, st = accum(48, 27, 5, 2)                        # batches of 2 + 2 + 1
+    b, _, _ = accum(48, 27, 5, 5)
+    c, _, _ = accum(48, 27, 5, 3)                         # 3 + 2
+    assert n == 5 and st.PixelsRendered == 48 * 27 * 5 and np.array_equal(a, b) and np.array_equal(a, c)
+    ref, _ = orc.render(RenderOptions(RenderWidth=48, RenderHeight=27, Passes=5, MaxBounceDepth=6, Seed=42), threads=4)
+    assert (np.abs(a - ref) <= 1e-3 * np.maximum(np.abs(ref), 1e-3) + 1e-5).all(axis=2).mean() > 0.97
+    one, n1, st1 = accum(1, 1, 7, 4)                      # one pixel
+    ref1, _ = orc.render(RenderOptions(RenderWidth=1, RenderHeight=1, Passes=7, MaxBounceDepth=6, Seed=42), threads=1)
+    assert one.shape == (1, 1, 3) and n1 == 7 and st1.PixelsRendered == 7
+    assert np.allclose(one, ref1, rtol=0.1, atol=1e-3)    # 7 paths: one grazing shadow ray may fall the other way (1-ulp light sampling), not more
+    s0, _, _ = accum(48, 27, 5, 2, first=0, n=3, stride=2)    # passes 0 2 4
+    s1, _, _ = accum(48, 27, 5, 2, first=1, n=2, stride=2)    # passes 1 3
+    assert np.allclose(s0 + s1, a, rtol=1e-5, atol=1e-6)
+    z, nz, stz = accum(48, 27, 5, 2, n=0)                 # nothing rendered: sums stay zero, the image resolves without dividing by zero
+    assert nz == 0 and stz.PixelsRendered == 0 and not z.any()
+    job = rt.RenderJob(sc, RenderOptions(RenderWidth=8, RenderHeight=8, Passes=0), device_scene=dev); job.Wait()
+    assert job.Image.shape == (8, 8, 3) and not job.Image.any() and not job.ReadAccum()[0].any()      # the freshly constructed Image<Rgb24>: black
+    job.Dispose()
