@@ -97,6 +97,7 @@ constexpr uint32_t OBJ_INDEX_MASK = (1u << OBJ_TYPE_SHIFT) - 1;
 
 struct SceneDev {
     const Node*    nodes;        uint32_t n_nodes;
+    uint32_t any_near_first;     // any-hit traversal visits the nearer child first (trees of >= 1024 nodes)
     const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
     const uint32_t* obj_material;
     uint32_t n_objects;
@@ -463,6 +464,7 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 #endif
 struct HbmTree {
     static constexpr bool vote = RT_TRAV_VOTE;
+    static constexpr bool any_order = true;
     int* stack; int stride;
     RT_FN void node(const SceneDev& sc, int i, float4& q0, float4& q1, float4& q2, int2& ch) const {
         const Node* np = sc.nodes + i;
@@ -482,6 +484,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
     return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
 }
 struct LdsTree {
+    static constexpr bool any_order = false;
     static constexpr bool vote = RT_LDS_VOTE;      // rays of equal cost: the votes only cost instructions here
     const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
     unsigned short* stack; int stride;
@@ -530,7 +533,10 @@ RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Ray& r, f3 invD
     }
     int next = ch.x; bool pop = false;
     if (hA && hB) {
-        const bool bFirst = !ANY && (enB < enA);               // nearer entry first (affects only the amount of work)
+        // nearer entry first (affects only the amount of work).  For any-hit rays it pays in big scenes, where an occluder close to the
+        // origin ends the ray at once (100 k spheres + 64 lights: 66 -> 53 box tests per shadow ray, k_shadow 659 -> 521 ms), and costs
+        // its two selects in small ones (Cornell +5 %), so the host sets the flag by tree size.
+        const bool bFirst = (!ANY || (Tree::any_order && sc.any_near_first)) && (enB < enA);
         tree.push(sp, bFirst ? ch.x : ch.y); sp++;
         next = bFirst ? ch.y : ch.x;
     } else if (hB) next = ch.y;

@@ -347,7 +347,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     UP(media_rec, mrec); UP(materials, mats); UP(textures, texs); UP(lights, lts);
 #undef UP
     SceneDev& sd = s->dev;
-    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)n_nodes;
+    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)n_nodes; sd.any_near_first = n_nodes >= 1024 ? 1u : 0u;
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>(); sd.n_objects = d->n_objects;
     sd.unbounded = s->unbounded.as<uint32_t>(); sd.n_unbounded = (uint32_t)unbounded.size();
     sd.media = s->media.as<uint32_t>(); sd.n_media = (uint32_t)media.size();
