@@ -81,7 +81,7 @@ struct rt_scene {
     bool device_build = false;       // the tree was built by rt_lbvh.hip
     int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
-    DevBuf lds_image;
+    DevBuf lds_image, list_nodes;
     uint32_t n_objects = 0, n_lights = 0;
     int n_cu = 256;
     DevBuf nodes, obj_code, obj_material, unbounded, media, spheres, quads, triangles, inf_planes, axis[3], disks, boxes, capsules, cylinders,
@@ -337,6 +337,26 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "device BVH build: %s", err.c_str());
     } else UP(nodes, nodes);
     s->device_build = device_build;
+    // a handful of objects: a list of all of them, two per record, instead of the tree (rt_device.h: list_closest)
+    {
+        const char* e = getenv("RT_HIP_LIST");
+        const size_t list_max = e ? (size_t)std::max(0, atoi(e)) : 16;
+        if (!boxes.empty() && boxes.size() <= list_max) {
+            std::vector<Node> ln((boxes.size() + 1) / 2);
+            for (size_t i = 0; i < ln.size(); i++) {
+                rtbvh::HostNode h; std::memset(&h, 0, sizeof(h));
+                for (int side = 0; side < 2; side++) {
+                    const size_t k = 2 * i + side;
+                    const bool have = k < boxes.size();
+                    for (int a = 0; a < 3; a++) { h.q[2 * a + side] = have ? boxes[k].mn[a] : INFINITY; h.q[6 + 2 * a + side] = have ? boxes[k].mx[a] : -INFINITY; }
+                    (side ? h.childB : h.childA) = have ? ~(int32_t)box_obj[k] : rtbvh::CHILD_EMPTY;
+                }
+                memcpy(&ln[i], &h, sizeof(Node));
+            }
+            UP(list_nodes, ln);
+            s->dev.list = s->list_nodes.as<Node>(); s->dev.n_list_pairs = (uint32_t)ln.size();
+        }
+    }
     UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
     UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis[0], axis[0]); UP(axis[1], axis[1]); UP(axis[2], axis[2]);
     UP(disks, disks); UP(boxes, bxs); UP(capsules, caps); UP(cylinders, cyls);
