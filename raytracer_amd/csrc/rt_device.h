@@ -100,6 +100,7 @@ struct SceneDev {
     uint32_t any_near_first;     // any-hit traversal visits the nearer child first (trees of >= 1024 nodes)
     const Node*    list;         uint32_t n_list_pairs;  // scenes of a few objects: every bounded object, two per record, instead of the tree (see list_closest)
     const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
+    uint32_t leaf_code_affine, leaf_code_base;   // every object in the tree: obj_code[obj] == leaf_code_base + obj (see leaf_code)
     const uint32_t* obj_material;
     uint32_t n_objects;
     const uint32_t* unbounded;   uint32_t n_unbounded;   // objects with a non-finite AABB (InfinitePlane.cs:28), tested for every ray
@@ -476,12 +477,16 @@ struct HbmTree {
     template <class C> RT_FN bool leaf_try(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax, float& k) const;
     template <class C> RT_FN bool leaf_fast(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax) const;
 };
+// (type, index) of a leaf's object.  When every object in the tree has the same type and its table index is its object id minus a
+// constant (a mesh, a field of spheres: the way bulk scenes are flattened) the code is computed instead of loaded: one dependent,
+// uncached 4-B fetch less between the node and the primitive record.
+RT_FN uint32_t leaf_code(const SceneDev& sc, uint32_t obj) { return sc.leaf_code_affine ? sc.leaf_code_base + obj : sc.obj_code[obj]; }
 template <class C> RT_FN bool HbmTree::leaf_try(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax, float& k) const {
-    uint32_t code = sc.obj_code[obj];
+    uint32_t code = leaf_code(sc, obj);
     return try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax, k);
 }
 template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t obj, Ray r, float kMin, float kMax) const {
-    uint32_t code = sc.obj_code[obj];
+    uint32_t code = leaf_code(sc, obj);
     return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
 }
 struct LdsTree {

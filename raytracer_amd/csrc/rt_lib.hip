@@ -337,6 +337,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "device BVH build: %s", err.c_str());
     } else UP(nodes, nodes);
     s->device_build = device_build;
+    {   // leaf_code: do the tree's objects all satisfy obj_code[obj] == base + obj ?
+        bool affine = !box_obj.empty();
+        const uint32_t base = affine ? obj_code[box_obj[0]] - box_obj[0] : 0u;
+        for (uint32_t obj : box_obj) if (obj_code[obj] - obj != base) { affine = false; break; }
+        s->dev.leaf_code_affine = affine ? 1u : 0u; s->dev.leaf_code_base = base;
+    }
     // a handful of objects: a list of all of them, two per record, instead of the tree (rt_device.h: list_closest)
     {
         const char* e = getenv("RT_HIP_LIST");
