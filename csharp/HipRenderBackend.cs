@@ -91,7 +91,7 @@ internal static unsafe class RtHip
 	[StructLayout(LayoutKind.Sequential)]
 	public unsafe struct SceneInfo
 	{
-		public uint NObjects, NUnbounded, NNodes, BvhDepth, TreeInLds, LdsImageBytes, BuiltOnDevice, Reserved;
+		public uint NObjects, NUnbounded, NNodes, BvhDepth, TreeInLds, LdsImageBytes, BuiltOnDevice, ObjectList;
 		public fixed byte Variant[16];
 	}
 

@@ -349,7 +349,7 @@ typedef struct rt_scene_info {
     uint32_t tree_in_lds;             /* 1: the tree and sphere table are copied into each workgroup's LDS */
     uint32_t lds_image_bytes;
     uint32_t built_on_device;         /* 1: Morton-order build on the GPU (>= 256 k bounded objects), 0: binned SAH on the host */
-    uint32_t reserved;
+    uint32_t object_list;             /* 1: <= 16 bounded objects, traced as a list (every object for every ray, as the reference's any-hit does) instead of the tree */
     char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
 } rt_scene_info;
 int rt_scene_get_info(rt_scene* scene, rt_scene_info* out);

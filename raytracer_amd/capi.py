@@ -135,7 +135,7 @@ class KernelProfile(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("n_unbounded", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
-                ("tree_in_lds", C.c_uint32), ("lds_image_bytes", C.c_uint32), ("built_on_device", C.c_uint32), ("reserved", C.c_uint32),
+                ("tree_in_lds", C.c_uint32), ("lds_image_bytes", C.c_uint32), ("built_on_device", C.c_uint32), ("object_list", C.c_uint32),
                 ("variant", C.c_char * 16)]
 
 

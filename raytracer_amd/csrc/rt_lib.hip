@@ -423,7 +423,7 @@ int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
     memset(out, 0, sizeof(*out));
     out->n_objects = s->n_objects; out->n_unbounded = s->dev.n_unbounded; out->n_nodes = s->dev.n_nodes; out->bvh_depth = s->bvh_depth;
     out->tree_in_lds = s->use_lds ? 1u : 0u; out->lds_image_bytes = s->dev.lds_image_bytes;
-    out->built_on_device = s->device_build ? 1u : 0u;
+    out->built_on_device = s->device_build ? 1u : 0u; out->object_list = s->dev.n_list_pairs ? 1u : 0u;
     strncpy(out->variant, s->ks->name, sizeof(out->variant) - 1);
     return RT_OK;
 }

@@ -54,7 +54,7 @@ class DeviceScene:
         si = capi.SceneInfo()
         capi.check(self._lib.rt_scene_get_info(self.handle, C.byref(si)))
         return {"n_objects": si.n_objects, "n_unbounded": si.n_unbounded, "n_nodes": si.n_nodes, "bvh_depth": si.bvh_depth,
-                "tree_in_lds": bool(si.tree_in_lds), "lds_image_bytes": si.lds_image_bytes, "built_on_device": bool(si.built_on_device),
+                "tree_in_lds": bool(si.tree_in_lds), "lds_image_bytes": si.lds_image_bytes, "built_on_device": bool(si.built_on_device), "object_list": bool(si.object_list),
                 "variant": si.variant.decode()}
 
     def TraceClosest(self, origins, directions, kMin=0.001, kMax=np.inf, seed=0):

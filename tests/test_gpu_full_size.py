@@ -93,7 +93,7 @@ def test_config2_night_spheres_1080p():
 @pytest.mark.parametrize("intensity,direct", [(0.1, False), (1.0, True)])
 def test_config3_cornell_depth32_1080p(intensity, direct):
     sc = bs.CornellBox(intensity, direct); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
-    assert dev.Info()["variant"] == "boxes"
+    assert dev.Info()["variant"] == "boxes" and dev.Info()["object_list"]
     _ray_parity(sc, flat, dev, orc, 50_000, 5_000, 22)
     opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=32, LightSampleCountHint=2, Seed=0xC3)
     got, st = _properties(sc, dev, opt)

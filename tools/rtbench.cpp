@@ -111,10 +111,10 @@ int main(int argc, char** argv) {
         if (!f) { fprintf(stderr, "rtbench: cannot write %s\n", ppm); return 1; }
         fprintf(f, "P6\n%u %u\n255\n", W, H); fwrite(rgb.data(), 1, rgb.size(), f); fclose(f);
     }
-    printf("{\"scene\": \"%s\", \"objects\": %u, \"bvh_nodes\": %u, \"bvh_depth\": %u, \"variant\": \"%s\", \"tree_in_lds\": %s, \"width\": %u, \"height\": %u, "
+    printf("{\"scene\": \"%s\", \"objects\": %u, \"bvh_nodes\": %u, \"bvh_depth\": %u, \"variant\": \"%s\", \"tree_in_lds\": %s, \"object_list\": %s, \"width\": %u, \"height\": %u, "
            "\"passes\": %u, \"seconds\": %.6f, \"msamples_per_s\": %.3f, \"closest_rays\": %" PRIu64 ", \"shadow_rays\": %" PRIu64 ", \"pixels_rendered\": %" PRIu64
            ", \"scene_create_s\": %.4f, \"rgb24_fnv1a\": \"%016" PRIx64 "\"}\n",
-           argv[1], info.n_objects, info.n_nodes, info.bvh_depth, info.variant, info.tree_in_lds ? "true" : "false", W, H, passes, dt,
+           argv[1], info.n_objects, info.n_nodes, info.bvh_depth, info.variant, info.tree_in_lds ? "true" : "false", info.object_list ? "true" : "false", W, H, passes, dt,
            (double)W * H * passes / dt / 1e6, (uint64_t)st.ray_count, (uint64_t)st.shadow_rays, (uint64_t)st.pixels_rendered, t_scene, fnv);
     rt_render_destroy(job);
     rt_scene_destroy(scene);
