@@ -467,6 +467,7 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 struct HbmTree {
     static constexpr bool vote = RT_TRAV_VOTE;
     static constexpr bool any_order = true;
+    static constexpr bool list = true;       // scenes of a handful of objects are walked as a list (list_closest)
     int* stack; int stride;
     RT_FN void node(const SceneDev& sc, int i, float4& q0, float4& q1, float4& q2, int2& ch) const {
         const Node* np = sc.nodes + i;
@@ -491,6 +492,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
 }
 struct LdsTree {
     static constexpr bool any_order = false;
+    static constexpr bool list = false;      // (the host never pairs the LDS tree with an object list: keeps these kernels' registers)
     static constexpr bool vote = RT_LDS_VOTE;      // rays of equal cost: the votes only cost instructions here
     const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
     unsigned short* stack; int stride;
@@ -643,7 +645,7 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
         float k; cnt.prims++;
         if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
     }
-    if (sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
+    if (Tree::list && sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
     else if (sc.n_nodes) {
         const f3 invD = splat(1.0f) / r.d;
         int sp = 0, cur = 0, pend = TRAV_DONE;
@@ -686,7 +688,7 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
             if (fast_object_solid<C>(sc, m.boundary_type, m.boundary_index, r, kMin, kMax)) return true;      // ConstantDensityMedium.cs:77
         }
     }
-    if (sc.n_list_pairs) return list_any<C>(sc, r, kMin, kMax, cnt);
+    if (Tree::list && sc.n_list_pairs) return list_any<C>(sc, r, kMin, kMax, cnt);
     if (!sc.n_nodes) return false;
     const f3 invD = splat(1.0f) / r.d;
     int sp = 0, cur = 0, pend = TRAV_DONE;

@@ -394,7 +394,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const size_t image_bytes = (3 * nn + (nn + 1) / 2 + no) * 16;
         const size_t need = image_bytes + (size_t)s->stack_depth * LDS_BLOCK_CLOSEST * sizeof(unsigned short);
         const char* no_lds = getenv("RT_HIP_NO_LDS_TREE");
-        if (all_spheres && nn < 32768 && no < 32768 && need <= 80 * 1024 && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+        if (all_spheres && !s->dev.n_list_pairs && nn < 32768 && no < 32768 && need <= 80 * 1024 && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
             std::vector<float4> img(image_bytes / 16, make_float4(0, 0, 0, 0));
             for (size_t i = 0; i < nn; i++) { img[i] = nodes[i].q0; img[nn + i] = nodes[i].q1; img[2 * nn + i] = nodes[i].q2; }
             int2* chp = (int2*)(img.data() + 3 * nn);
