@@ -94,9 +94,11 @@ def main(argv=None):
     job.passes_per_call = a.progress_passes or int(job._opts.passes_per_batch) or a.passes
     t0 = time.perf_counter()
     task = job.StartOrGetRenderAsync()
+    finished = []
+    task.add_done_callback(lambda _: finished.append(time.perf_counter()))      # the moment the render task completed, not the next poll
     try:
         while not task.done():
-            time.sleep(0.25)
+            time.sleep(0.05)
             done = job.PassesSoFar
             if done:
                 el = time.perf_counter() - t0
@@ -106,7 +108,7 @@ def main(argv=None):
         job._cancel.set()
         print("\ncancelled", file=sys.stderr)
         return 130
-    el = time.perf_counter() - t0
+    el = (finished[0] if finished else time.perf_counter()) - t0
     st = job.RenderStats
     print(f"\r{a.passes} passes in {el:.2f} s: {a.width * a.height * a.passes / el / 1e6:.1f} Msamples/s, {st.RayCount / el / 1e6:.0f} M closest rays/s, "
           f"{st.ShadowRays / el / 1e6:.0f} M shadow rays/s; sky {st.SkyRays}, bounce limit {st.BounceLimitExceeded}")
