@@ -185,9 +185,9 @@ def main():
                             "this scene's tree lives in LDS, so they never reach HBM; `traffic` is what does (path state), from PMC counters."}
 
         def shade_roofline():
-            # k_shade moves path state: 72 B read per alive path, 64 B written per survivor, 48 B per shadow request, 16 B per finished path
+            # k_shade moves path state: 64 B read per alive path (56 state + 8 hit), 56 B written per survivor, 48 B per shadow request, 16 B per finished path
             alive, scat, fin = pd["ray_count"], pd["scatter"], pd["pixels"]
-            byts = 72 * alive + 64 * (scat - pd["limit"]) + 48 * (pd["shadow_rays"] // LIGHT_SAMPLES) + 16 * fin
+            byts = 64 * alive + 56 * (scat - pd["limit"]) + 48 * (pd["shadow_rays"] // LIGHT_SAMPLES) + 16 * fin
             sec, launches = prof["shade"]["total_ms"] / 1e3, max(prof["shade"]["launches"], 1)
             return {"kernel": "k_shade", "bound": "hbm", "achieved": byts / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / sec / 1e9 / HBM_PEAK_GBS,
                     "traffic": traffic.get("k_shade"), "launches": launches, "avg_launch_ms": prof["shade"]["total_ms"] / launches,

@@ -26,13 +26,14 @@ enum StatSlot : int {
     ST_DEPTH0, ST_COUNT = ST_DEPTH0 + RT_DEPTH_HIST_SIZE
 };
 
-// Path state at queue position j (4 x float4 = 64 B):
-//   g0 = (origin.xyz, dir.x)  g1 = (dir.y, dir.z, T.r, T.g)  g2 = (T.b, L.r, L.g, L.b)  g3 = (path id, prev material, first material, -) as bits
+// Path state at queue position j (3 x float4 + uint2 = 56 B):
+//   g0 = (origin.xyz, dir.x)  g1 = (dir.y, dir.z, T.r, T.g)  g2 = (T.b, L.r, L.g, L.b)  ids = (path id, previous material | first material << 16)
 // Shadow request at shadow-queue position p (3 x float4, + 1 for Phong):
 //   h0 = (hit point.xyz, normal.x)  h1 = (normal.y, normal.z, W.r, W.g)  h2 = (W.b, path id, dst, hit object) as bits   h3 = (incoming dir.xyz, -)
 //   dst = position in the NEXT state whose L receives the light sum, or RT_NO_HIT when the path ended (then out[path id] does)
 struct RenderDev {
-    float4* st[2][4];
+    float4* st[2][3];
+    uint2*  ids[2];           // (path id, pack_mats(previous hit's material, first hit's material)): what the refractive materials ask about the path
     float2* hit;              // (K, object id bits) by queue position
     float*  hit_aux;          // HitRecord.ShaderData (media only) by queue position
     float4* out;              // final radiance by path id
@@ -48,6 +49,10 @@ struct RenderDev {
     uint32_t max_depth, light_samples;
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
+
+// material ids are < 0xFFFF (rt_scene_create), 0xFFFF = none yet
+RT_FN uint32_t pack_mats(uint32_t prev, uint32_t first) { return (prev == RT_NO_HIT ? 0xFFFFu : prev) | ((first == RT_NO_HIT ? 0xFFFFu : first) << 16); }
+RT_FN uint32_t unpack_mat(uint32_t half) { half &= 0xFFFFu; return half == 0xFFFFu ? RT_NO_HIT : half; }
 
 RT_FN uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -102,7 +107,7 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
         rd.st[0][0][id] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
         rd.st[0][1][id] = make_float4(r.d.y, r.d.z, 1.0f, 1.0f);
         rd.st[0][2][id] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        rd.st[0][3][id] = make_float4(__uint_as_float(id), __uint_as_float(RT_NO_HIT), __uint_as_float(RT_NO_HIT), 0.0f);
+        rd.ids[0][id] = make_uint2(id, pack_mats(RT_NO_HIT, RT_NO_HIT));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = rd.n_paths;
 }
@@ -132,13 +137,13 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
-    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
+    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
     uint32_t rays = 0, nodes = 0, prims = 0;
     for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
         float4 a = g0[j], b = g1[j];
         Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
         RngKey key = make_key(0, 0, 0);
-        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, __float_as_uint(g3[j].x));     // only a medium draws random numbers
+        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, g3[j].x);     // only a medium draws random numbers
         TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         Closest c = closest_hit<C>(sc, tree, r, rd.k_min, rd.k_max, key, depth, cnt);
         rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
-    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const float4* g3 = rd.st[depth & 1][3];
+    const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
     const float kMin = rd.k_min, kMax = rd.k_max;
     // every wave owns a contiguous run of the queue and hands its next rays to whichever lanes are idle: a refill then loads
     // consecutive positions (coalesced), and the rays a wave works on at one time stay neighbours in the image
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
             if (active) {
                 if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
                     if (!ray_has_nan(r)) {
-                        RngKey key = path_key(rd, __float_as_uint(g3[my_j].x));        // only a medium draws random numbers
+                        RngKey key = path_key(rd, g3[my_j].x);        // only a medium draws random numbers
                         for (uint32_t i = 0; i < sc.n_media; i++) {
                             uint32_t obj = sc.media[i], code = sc.obj_code[obj];
                             float k, aux; prims++;
@@ -323,12 +328,12 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
         p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
         p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
         if (j < n) {
-            const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j], a3 = rd.st[cur][3][j];
+            const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j]; const uint2 a3 = rd.ids[cur][j];
             const float2 hk = rd.hit[j];
             Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
             col3 T = mkc(a1.z, a1.w, a2.x);
             col3 L = mkc(a2.y, a2.z, a2.w);
-            const uint32_t id = __float_as_uint(a3.x);
+            const uint32_t id = a3.x;
             Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
             if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) c.aux = rd.hit_aux[j];
             if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 RngKey key = path_key(rd, id);
                 HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth);
                 const rt_material* m = sc.materials + h.mat;
-                uint32_t prev = __float_as_uint(a3.y), first = __float_as_uint(a3.z);
+                uint32_t prev = unpack_mat(a3.y), first = unpack_mat(a3.y >> 16);
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
                 Ray nr; nr.o = h.wp; nr.d = r.d;
                 col3 a = mkc(1, 1, 1);        // multiplier of the future colour
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                     rd.st[nxt][0][p0] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
                     rd.st[nxt][1][p0] = make_float4(nr.d.y, nr.d.z, T.r, T.g);
                     rd.st[nxt][2][p0] = make_float4(T.b, L.r, L.g, L.b);
-                    rd.st[nxt][3][p0] = make_float4(a3.x, __uint_as_float(h.mat), depth == 0 ? __uint_as_float(h.mat) : a3.z, 0.0f);
+                    rd.ids[nxt][p0] = make_uint2(id, pack_mats(h.mat, depth == 0 ? h.mat : first));
                 } else {                                                                  // RenderJob.cs:416-421: the next depth exceeds the limit, future = NoColour
                     limit++; samples++;                                                   // maxDepthReached = depth
                     rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);

@@ -203,6 +203,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     NEED(d->infinite_planes, d->n_infinite_planes); NEED(d->xy_planes, d->n_xy_planes); NEED(d->xz_planes, d->n_xz_planes); NEED(d->yz_planes, d->n_yz_planes);
     NEED(d->disks, d->n_disks); NEED(d->boxes, d->n_boxes); NEED(d->capsules, d->n_capsules); NEED(d->cylinders, d->n_cylinders); NEED(d->media, d->n_media);
     NEED(d->materials, d->n_materials); NEED(d->textures, d->n_textures); NEED(d->lights, d->n_lights);
+    if (d->n_materials >= 0xFFFFu) return fail(RT_ERR_TOO_LARGE, "%u materials: the path state keeps material ids in 16 bits (at most 65534)", d->n_materials);
 #undef NEED
     if (d->skybox.type > RT_SKY_SINGLE_COLOUR) return fail(RT_ERR_UNSUPPORTED, "unknown skybox type %u (user-defined SkyBoxes are rejected)", d->skybox.type);
     for (uint32_t i = 0; i < d->n_textures; i++)
@@ -537,8 +538,8 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     // path state: float4 arrays (2 x 4 state, 1 out, 3 (+1) shadow), then hit (float2) and hit_aux (float).  passes_per_batch is an
     // upper bound: when the device cannot hold it (another job, a smaller card) the batch is halved until it fits.
     const bool has_phong = (s->ks->mats >> RT_MAT_PHONG) & 1u, has_medium = (s->ks->prims >> RT_HIT_MEDIUM) & 1u;
-    const size_t n_f4 = 8 + 1 + 3 + (has_phong ? 1 : 0);
-    const size_t bytes_per_path = n_f4 * sizeof(float4) + sizeof(float2) + (has_medium ? sizeof(float) : 0);
+    const size_t n_f4 = 6 + 1 + 3 + (has_phong ? 1 : 0);
+    const size_t bytes_per_path = n_f4 * sizeof(float4) + 2 * sizeof(uint2) + sizeof(float2) + (has_medium ? sizeof(float) : 0);
     for (;;) {
         bool ok = true;
         for (int si = 0; si < n_slots && ok; si++) ok = r->slots[si].f32_pool.alloc((size_t)(n_pixels * ppb) * bytes_per_path) == hipSuccess;
@@ -578,11 +579,12 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
         RenderDev& rd = sl.rd;
         float4* f = sl.f32_pool.as<float4>();
         auto nf = [&]() { float4* p = f; f += P; return p; };
-        for (int h = 0; h < 2; h++) for (int i = 0; i < 4; i++) rd.st[h][i] = nf();
+        for (int h = 0; h < 2; h++) for (int i = 0; i < 3; i++) rd.st[h][i] = nf();
         rd.out = nf();
         for (int i = 0; i < 3; i++) rd.sh[i] = nf();
         rd.sh[3] = has_phong ? nf() : nullptr;
-        rd.hit = (float2*)f;
+        rd.ids[0] = (uint2*)f; rd.ids[1] = rd.ids[0] + P;
+        rd.hit = (float2*)(rd.ids[1] + P);
         rd.hit_aux = has_medium ? (float*)(rd.hit + P) : nullptr;
         rd.qcount = sl.counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
         rd.stats = r->stats.as<unsigned long long>();
