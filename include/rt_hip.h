@@ -250,7 +250,7 @@ typedef struct rt_scene_desc {
     uint32_t n_capsules;        const rt_capsule*        capsules;
     uint32_t n_cylinders;       const rt_cylinder*       cylinders;
     uint32_t n_media;           const rt_medium*         media;
-    uint32_t n_materials;       const rt_material*       materials;
+    uint32_t n_materials;       const rt_material*       materials;        /* at most 65 534 (RT_ERR_TOO_LARGE beyond): the path state keeps material ids in 16 bits */
     uint32_t n_textures;        const rt_texture*        textures;
     uint32_t n_lights;          const rt_light*          lights;
 } rt_scene_desc;

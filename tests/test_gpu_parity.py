@@ -239,3 +239,18 @@ def test_ragged_batches_tiny_images_and_zero_passes(pairs):
     job = rt.RenderJob(sc, RenderOptions(RenderWidth=8, RenderHeight=8, Passes=0), device_scene=dev); job.Wait()
     assert job.Image.shape == (8, 8, 3) and not job.Image.any() and not job.ReadAccum()[0].any()      # the freshly constructed Image<Rgb24>: black
     job.Dispose()
+
+
+def test_more_materials_than_the_path_state_can_name_are_refused():
+    """Material ids travel in 16 bits beside the path id: 65 535 distinct materials are refused, not truncated."""
+    from raytracer_amd import impl
+    from raytracer_amd.core import Colour, Scene, SceneObject
+    n = 65_535
+    mats = [impl.StandardMaterial(Colour(0.5), 1.0) for _ in range(n)]
+    c = np.zeros((n, 3), np.float32); c[:, 0] = np.arange(n) * 3.0
+    spheres = impl.SphereArray(c, np.ones(n, np.float32), mats, np.arange(n))
+    sc = Scene("many materials", bs.Demo().Camera, [], [], impl.DefaultSkyBox(), BulkObjects=[spheres])
+    from raytracer_amd import capi
+    with pytest.raises(capi.RtError) as e:
+        rt.DeviceScene(sc)
+    assert e.value.code == -6 and "16 bits" in str(e.value)
