@@ -254,3 +254,29 @@ def test_more_materials_than_the_path_state_can_name_are_refused():
     with pytest.raises(capi.RtError) as e:
         rt.DeviceScene(sc)
     assert e.value.code == -6 and "16 bits" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["Zoo", "Demo", "CornellBox", "Noise"])
+def test_small_scenes_through_the_tree_as_well(pairs, name, monkeypatch):
+    """Scenes of <= 16 objects are traced as an object list by default; RT_HIP_LIST=0 sends them through the BVH kernels, which must
+    give the same hits (this keeps every intersector covered inside the tree traversal too)."""
+    sc, flat, dev_list, orc = pairs(name)
+    assert dev_list.Info()["object_list"]
+    monkeypatch.setenv("RT_HIP_LIST", "0")
+    dev = rt.DeviceScene(flat)
+    monkeypatch.delenv("RT_HIP_LIST")
+    assert not dev.Info()["object_list"]
+    o, d = ray_set(sc, flat, 50_000, 41)
+    g, l, r = dev.TraceClosest(o, d, 0.001, np.inf, seed=8), dev_list.TraceClosest(o, d, 0.001, np.inf, seed=8), orc.trace_closest(o, d, 0.001, np.inf, seed=8)
+    helpers.assert_closest_parity(g, r)
+    helpers.assert_closest_parity(l, r)
+    kmin = np.full(len(o), 0.01, np.float32); kmax = np.random.default_rng(9).uniform(0.1, 30.0, len(o)).astype(np.float32)
+    ref = orc.trace_any(o, d, kmin, kmax)
+    assert np.array_equal(dev.TraceAny(o, d, kmin, kmax), ref) and np.array_equal(dev_list.TraceAny(o, d, kmin, kmax), ref)
+    opt = RenderOptions(RenderWidth=64, RenderHeight=36, Passes=3, MaxBounceDepth=6, Seed=9)
+    a = rt.RenderJob(sc, opt, device_scene=dev); a.Wait()
+    b = rt.RenderJob(sc, opt, device_scene=dev_list); b.Wait()
+    ga, gb = a.ReadAccum()[0], b.ReadAccum()[0]
+    fin = np.isfinite(ga).all(axis=2) & np.isfinite(gb).all(axis=2)
+    assert (np.abs(ga - gb)[fin] <= 1e-4 * np.maximum(np.abs(gb)[fin], 1e-3)).all(axis=1).mean() > 0.995
+    a.Dispose(); b.Dispose(); dev.Dispose()
