@@ -280,3 +280,22 @@ def test_small_scenes_through_the_tree_as_well(pairs, name, monkeypatch):
     fin = np.isfinite(ga).all(axis=2) & np.isfinite(gb).all(axis=2)
     assert (np.abs(ga - gb)[fin] <= 1e-4 * np.maximum(np.abs(gb)[fin], 1e-3)).all(axis=1).mean() > 0.995
     a.Dispose(); b.Dispose(); dev.Dispose()
+
+
+@pytest.mark.parametrize("name", ["Zoo", "MiniMesh", "MiniManyLights", "CornellBox", "Demo"])
+def test_persistent_lane_kernels_change_no_bit(pairs, name, monkeypatch):
+    """k_closest_persistent / k_shadow_persistent are picked by scene size and rays per request; forced on (every variant, tree
+    traversal) they must reproduce the plain kernels' image exactly: a ray's result does not depend on the schedule."""
+    sc, flat, _, _ = pairs(name)
+    opt = RenderOptions(RenderWidth=96, RenderHeight=54, Passes=4, MaxBounceDepth=8, LightSampleCountHint=2, Seed=77)
+    monkeypatch.setenv("RT_HIP_LIST", "0")
+    monkeypatch.setenv("RT_HIP_PERSISTENT", "0"); monkeypatch.setenv("RT_HIP_PERSISTENT_SHADOW", "0")
+    dev0 = rt.DeviceScene(flat)
+    a = rt.RenderJob(sc, opt, device_scene=dev0); a.Wait(); ia, sa = a.ReadAccum()[0], a.RenderStats
+    monkeypatch.setenv("RT_HIP_PERSISTENT", "1"); monkeypatch.setenv("RT_HIP_PERSISTENT_SHADOW", "1")
+    dev1 = rt.DeviceScene(flat)
+    b = rt.RenderJob(sc, opt, device_scene=dev1); b.Wait(); ib, sb = b.ReadAccum()[0], b.RenderStats
+    assert np.array_equal(ia, ib, equal_nan=True)
+    assert (sa.RayCount, sa.ShadowRays, sa.MaterialScatterCount) == (sb.RayCount, sb.ShadowRays, sb.MaterialScatterCount)
+    for x in (a, b): x.Dispose()
+    dev0.Dispose(); dev1.Dispose()
