@@ -299,3 +299,20 @@ def test_persistent_lane_kernels_change_no_bit(pairs, name, monkeypatch):
     assert (sa.RayCount, sa.ShadowRays, sa.MaterialScatterCount) == (sb.RayCount, sb.ShadowRays, sb.MaterialScatterCount)
     for x in (a, b): x.Dispose()
     dev0.Dispose(); dev1.Dispose()
+
+
+@pytest.mark.parametrize("knob,value", [("RT_HIP_NO_LDS_TREE", "1"), ("RT_HIP_VARIANT", "generic"), ("RT_HIP_SLOTS", "1"), ("RT_HIP_SLOTS", "3")])
+def test_kernel_choices_do_not_show_in_the_image(pairs, knob, value, monkeypatch):
+    """Tree in LDS or in HBM, scene-specialised or generic kernels, one or three batches in flight: the same arithmetic per operator
+    in every variant, the sums added in the same order, so not a bit of the image may differ."""
+    sc, flat, dev_default, _ = pairs("Testing")
+    assert dev_default.Info()["tree_in_lds"] and dev_default.Info()["variant"] == "spheres"
+    opt = RenderOptions(RenderWidth=160, RenderHeight=90, Passes=6, MaxBounceDepth=10, LightSampleCountHint=2, Seed=78, PassesPerBatch=2)
+    a = rt.RenderJob(sc, opt, device_scene=dev_default); a.Wait(); ia = a.ReadAccum()[0]; a.Dispose()
+    monkeypatch.setenv(knob, value)
+    dev = rt.DeviceScene(flat)
+    info = dev.Info()
+    if knob == "RT_HIP_NO_LDS_TREE": assert not info["tree_in_lds"]
+    if knob == "RT_HIP_VARIANT": assert info["variant"] == "generic"
+    b = rt.RenderJob(sc, opt, device_scene=dev); b.Wait(); ib = b.ReadAccum()[0]; b.Dispose(); dev.Dispose()
+    assert np.array_equal(ia, ib, equal_nan=True)
