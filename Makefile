@@ -15,8 +15,19 @@ BENCH := tools/rtbench
 
 all: $(LIB) $(ORC) $(BENCH)
 
-$(LIB): $(CSRC)/rt_lib.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h $(CSRC)/rt_lbvh.hip include/rt_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_lib.hip $(CSRC)/rt_lbvh.hip $(CSRC)/rt_bvh.cpp
+HDRS := $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.h include/rt_hip.h
+OBJS := $(addprefix build/,rt_lib.o rt_lbvh.o rt_bvh.o rt_variant_spheres.o rt_variant_mesh.o rt_variant_boxes.o rt_variant_all.o)
+
+build/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+build/rt_bvh.o: $(CSRC)/rt_bvh.cpp $(CSRC)/rt_bvh.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
 
 $(ORC): oracle/oracle.cpp include/rt_hip.h
 	$(CXX) $(ORCFLAGS) -shared -o $@ oracle/oracle.cpp
@@ -26,6 +37,6 @@ $(BENCH): tools/rtbench.cpp include/rt_hip.h $(LIB)
 	$(CXX) -O2 -std=c++17 -Wall -o $@ tools/rtbench.cpp -Lraytracer_amd -lrt_hip -Wl,-rpath,'$$ORIGIN/../raytracer_amd'
 
 clean:
-	rm -f $(LIB) $(ORC) $(BENCH)
+	rm -rf $(LIB) $(ORC) $(BENCH) build
 
 .PHONY: all clean

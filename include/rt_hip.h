@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef struct rt_scene  rt_scene;   /* opaque: flattened Scene + BVH on one device */
 typedef struct rt_render rt_render;  /* opaque: one RenderJob's device state */
@@ -277,6 +277,13 @@ typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61, same
  * Material.GetHashCode(), o = 1 for the alternate checker cell.  GetHashCode of a reference type is a per-process identity hash, so it
  * cannot be reproduced; this library uses hash = (material id + 1) * 2654435761 (mod 2^32) in its place. */
 
+#define RT_MAX_DEVICES 16
+/* rt_render_opts.flags */
+#define RT_RENDER_EXACT_LIGHT_SAMPLING 1u   /* shadow rays and light weights in the reference's correctly rounded arithmetic (Normalize, Distance,
+                                               kMax / AttenuationRadius, MathF.Pow(MathF.E, y), sum / samples) instead of the hardware's 1-ulp
+                                               rsq / rcp / exp2: bit-identical shadow rays to a CPU restatement, ~10 % slower shadow kernel.
+                                               The environment variable RT_HIP_EXACT_LIGHTS=1 sets it for every render. */
+
 typedef struct rt_render_opts {
     uint32_t struct_size;            /* sizeof(rt_render_opts) */
     uint32_t width, height;          /* RenderWidth, RenderHeight (>= 1) */
@@ -285,12 +292,23 @@ typedef struct rt_render_opts {
     uint32_t light_sample_count_hint;/* LightSampleCountHint (2), >= 1 */
     uint32_t debug_visualisation;    /* rt_debug_vis */
     uint64_t seed;                   /* key of the counter RNG that replaces Random.Shared (RandUtils.cs:17) */
-    uint32_t passes_per_batch;       /* passes traced per wavefront batch; 0 = library default */
-    int32_t  device;                 /* HIP device ordinal, -1 = current device */
-    void*    stream;                 /* hipStream_t to enqueue on, NULL = a stream owned by the library */
+    uint32_t passes_per_batch;       /* passes traced per wavefront batch; 0 = library default (see max_passes_per_call) */
+    int32_t  device;                 /* HIP device ordinal, -1 = the scene's device (ignored when n_devices > 1) */
+    void*    stream;                 /* hipStream_t to enqueue on, NULL = a stream owned by the library (must be NULL when n_devices > 1) */
     float*   accum_device;           /* optional caller-owned DEVICE buffer of width*height*3 floats (zeroed by the
                                         caller) that receives the colour sums, e.g. a buffer a collective reduces;
-                                        NULL = owned by the library */
+                                        NULL = owned by the library (must be NULL when n_devices > 1) */
+    /* ---- ABI 2 ---- */
+    uint32_t flags;                  /* RT_RENDER_* */
+    uint32_t max_passes_per_call;    /* the largest n_passes this caller gives rt_render_passes, 0 = unknown.  The default batch holds
+                                        min(64, 128 M paths / pixels, this) passes: a GUI that renders 8 passes per call does not pay
+                                        for 64 passes of path state (184 B per path and batch slot) */
+    uint32_t n_devices;              /* 0 or 1: one GPU, the scene's.  G > 1: the passes of every rt_render_passes call are sharded over
+                                        device_ids[0..G) inside the library (pass first + i*stride goes to device i mod G; the scene is
+                                        replicated by peer copies, one host thread and stream set per device) and the readers
+                                        (rt_render_read_rgb24 / _accum / _stats) combine the shards on device_ids[0] in device order.
+                                        An ordinal may repeat (two shards on one GPU: how the 1-GPU test box exercises this path). */
+    int32_t  device_ids[RT_MAX_DEVICES];
 } rt_render_opts;
 
 /* RenderStats (Ararem.RayTracer.Core/RenderStats.cs:12-93), field for field, plus counters the
@@ -301,9 +319,11 @@ typedef struct rt_stats {
     uint64_t passes_rendered;        /* :120 */
     uint64_t material_scatter_count; /* :439 */
     uint64_t material_absorbed_count;/* :431 */
-    uint64_t aabb_misses;            /* BinaryBvhNode.cs:18, SingleObjectBvhNode.cs:15 (device BVH topology differs) */
-    uint64_t hittable_misses;        /* SingleObjectBvhNode.cs:28 */
-    uint64_t hittable_intersections; /* SingleObjectBvhNode.cs:23 */
+    uint64_t aabb_misses;            /* BinaryBvhNode.cs:18, SingleObjectBvhNode.cs:15: box tests of the closest-hit traversal that failed.  The device tree has
+                                        another topology than the reference's (BvhTree.cs:181-186 is implementation-defined), so the count differs from the
+                                        reference's for the same scene; aabb_misses <= node_visits */
+    uint64_t hittable_misses;        /* SingleObjectBvhNode.cs:28: Hittable.TryHit calls that returned null; hittable_misses + hittable_intersections == prim_tests */
+    uint64_t hittable_intersections; /* SingleObjectBvhNode.cs:23: Hittable.TryHit calls that returned a hit */
     uint64_t sky_rays;               /* RenderJob.cs:447 */
     uint64_t bounce_limit_exceeded;  /* :418 */
     uint64_t ray_count;              /* :583  closest-hit rays */
@@ -348,7 +368,7 @@ typedef struct rt_scene_info {
     uint32_t n_nodes, bvh_depth;      /* inner nodes (64 B each) and deepest inner level */
     uint32_t tree_in_lds;             /* 1: the tree and sphere table are copied into each workgroup's LDS */
     uint32_t lds_image_bytes;
-    uint32_t built_on_device;         /* 1: Morton-order build on the GPU (>= 256 k bounded objects), 0: binned SAH on the host */
+    uint32_t built_on_device;         /* 1: Morton-order build on the GPU (only with RT_HIP_BVH=device), 0: binned SAH on the host (the default for every size) */
     uint32_t object_list;             /* 1: <= 16 bounded objects, traced as a list (every object for every ray, as the reference's any-hit does) instead of the tree */
     char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
 } rt_scene_info;

@@ -27,6 +27,9 @@ def load():
         lib.orc_scene_destroy.argtypes = [C.c_void_p]
         lib.orc_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
         lib.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.orc_trace_any_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+        lib.orc_trace_any_culled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+        lib.orc_scene_set_culled_any.argtypes = [C.c_void_p, C.c_int]
         lib.orc_render.argtypes = [C.c_void_p, C.POINTER(capi.RenderOpts), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(capi.Stats)]
         lib.orc_resolve_rgb24.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.orc_camera_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(capi.Camera)]
@@ -53,14 +56,21 @@ class OracleScene:
         _check(load().orc_trace_closest(self.handle, rays.ctypes.data, len(rays), kMin, kMax, seed, hits.ctypes.data))
         return hits
 
-    def trace_any(self, origins, directions, kMin, kMax):
+    def trace_any(self, origins, directions, kMin, kMax, threads=1, culled=False):
+        """RenderJob.AnyIntersectionFast on a batch of rays.  culled=False: the reference's scan of every object (RenderJob.cs:575);
+        culled=True: the same boolean through the checker's own box tree (oracle.cpp CullTree; tests prove the two equal)."""
         rays = _pack_rays(origins, directions)
         n = len(rays)
         k0 = np.ascontiguousarray(np.broadcast_to(np.asarray(kMin, np.float32), (n,)))
         k1 = np.ascontiguousarray(np.broadcast_to(np.asarray(kMax, np.float32), (n,)))
         out = np.zeros(n, dtype=np.uint8)
-        _check(load().orc_trace_any(self.handle, rays.ctypes.data, k0.ctypes.data, k1.ctypes.data, n, out.ctypes.data))
+        fn = load().orc_trace_any_culled if culled else load().orc_trace_any_mt
+        _check(fn(self.handle, rays.ctypes.data, k0.ctypes.data, k1.ctypes.data, n, out.ctypes.data, threads))
         return out.astype(bool)
+
+    def set_culled_any(self, enable: bool):
+        """Shadow rays of render() through CullTree instead of the every-object scan (full-size scenes only; same booleans)."""
+        _check(load().orc_scene_set_culled_any(self.handle, 1 if enable else 0))
 
     def render(self, options, first_pass=0, n_passes=None, stride=1, threads=1, accum=None):
         """RenderInternal on the CPU: returns (rgb_sum (H, W, 3) float32 in image-row order, stats dict)."""

@@ -716,6 +716,96 @@ static float perlin_noise(float x, float y, float z, float frequency, float lacu
 }
 static float marble_noise(float x, float y, float z) { return perlin_noise(x, y, z, 1.0f, 3.0f, 0.5f, 5, 0); }      // MarbleTexture.cs:11-17
 
+
+// ---------------------------------------------------------------------------------------------
+// CullTree — NOT in the reference.  RenderJob.AnyIntersectionFast (Core/RenderJob.cs:575) asks every object's FastTryHit
+// (BinaryBvhNode.cs:41 has no box test), which costs O(objects) per shadow ray: 5 M triangle tests per ray on config 4.  To check
+// the device's any-hit answers on >= 100 k rays of the full-size scenes the checker needs the same boolean faster.  This is a plain
+// median-split box tree over the objects' BoundingVolumes whose box test is CLOSED and whose boxes are GROWN (see MayHit) three
+// times as far as the device grows its own, i.e. strictly more conservative than the device's; an object is still decided by
+// its own FastTryHit.  tests/ prove it equal to the list scan (every small scene, 100 k rays each, and a sample of rays
+// on the full-size scenes) before they use it as the reference for the device.
+// ---------------------------------------------------------------------------------------------
+struct CullTree {
+    struct Node { Aabb box; uint32_t left, right, first, count; };       // count > 0: leaf over order[first .. first+count)
+    std::vector<Node> nodes;
+    std::vector<SceneObjectRef> order;
+    std::vector<SceneObjectRef> always;                                   // objects with a non-finite box (InfinitePlane.cs:28) and media
+    static bool Finite(const Aabb& b) {
+        return std::isfinite(b.Min.x) && std::isfinite(b.Min.y) && std::isfinite(b.Min.z) && std::isfinite(b.Max.x) && std::isfinite(b.Max.y) && std::isfinite(b.Max.z);
+    }
+    uint32_t BuildRange(uint32_t lo, uint32_t hi) {
+        Node n{}; n.box = order[lo].h->BoundingVolume;
+        V3 cmin = (n.box.Min + n.box.Max) / 2.0f, cmax = cmin;
+        for (uint32_t i = lo + 1; i < hi; i++) {
+            const Aabb& b = order[i].h->BoundingVolume;
+            n.box = Aabb::Encompass(n.box, b);
+            V3 c = (b.Min + b.Max) / 2.0f; cmin = Min3(cmin, c); cmax = Max3(cmax, c);
+        }
+        const uint32_t id = (uint32_t)nodes.size();
+        nodes.push_back(n);
+        if (hi - lo <= 4) { nodes[id].first = lo; nodes[id].count = hi - lo; return id; }
+        V3 e = cmax - cmin;
+        const int axis = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
+        const uint32_t mid = (lo + hi) / 2;
+        auto key = [axis](const SceneObjectRef& r) { const Aabb& b = r.h->BoundingVolume; return axis == 0 ? b.Min.x + b.Max.x : axis == 1 ? b.Min.y + b.Max.y : b.Min.z + b.Max.z; };
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](const SceneObjectRef& a, const SceneObjectRef& b) { return key(a) < key(b); });
+        const uint32_t l = BuildRange(lo, mid), r = BuildRange(mid, hi);
+        nodes[id].left = l; nodes[id].right = r;
+        return id;
+    }
+    V3 centre{0, 0, 0}; float radius = 0, maxObjectRadius = 0;            // sphere around every bounded object; largest half-diagonal of one object's box
+    void Build(const std::vector<SceneObjectRef>& solids, const std::vector<SceneObjectRef>& media) {
+        for (const SceneObjectRef& s : solids) (Finite(s.h->BoundingVolume) ? order : always).push_back(s);
+        for (const SceneObjectRef& m : media) always.push_back(m);
+        nodes.reserve(order.size());
+        if (order.empty()) return;
+        BuildRange(0, (uint32_t)order.size());
+        const Aabb& all = nodes[0].box;
+        centre = (all.Min + all.Max) / 2.0f; radius = Length(all.Max - all.Min) * 0.5001f + 1e-6f;
+        for (const SceneObjectRef& s : order) maxObjectRadius = std::max(maxObjectRadius, Length(s.h->BoundingVolume.Max - s.h->BoundingVolume.Min) * 0.5001f);
+    }
+    // A binary32 intersector can accept a point outside its object's box: the sphere test's discriminant halfB^2 - a c carries an
+    // absolute error of up to ~1e-6 D^2 at distance D from the ray origin, so a ray passing the sphere at sqrt(r^2 + 1e-6 D^2) may
+    // be reported as a hit, ~1e-3 D outside the box (seen on shadow rays from ground points 2 000 units out in the Demo scene).
+    // Every box is therefore grown by pad = 3e-3 * D + 1e-4 (three times the device's), D = the farthest an object the ray can
+    // report may be: its range, capped by the far side of the scene, plus twice the largest object.
+    static bool MayHit(const Aabb& b, const Ray& ray, V3 invD, float kMin, float kMax, float pad) {
+        float lo = kMin, hi = kMax;
+        const float mn[3] = {b.Min.x - pad, b.Min.y - pad, b.Min.z - pad}, mx[3] = {b.Max.x + pad, b.Max.y + pad, b.Max.z + pad};
+        const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, id[3] = {invD.x, invD.y, invD.z};
+        for (int a = 0; a < 3; a++) {
+            float t0 = (mn[a] - o[a]) * id[a], t1 = (mx[a] - o[a]) * id[a];
+            if (std::isnan(t0) || std::isnan(t1)) continue;               // 0 * inf: this axis cannot decide, so it does not cull
+            if (t0 > t1) std::swap(t0, t1);
+            if (t0 > lo) lo = t0;
+            if (t1 < hi) hi = t1;
+        }
+        if (std::isnan(lo) || std::isnan(hi)) return true;
+        const float slack = 1e-5f * (std::fabs(lo) + std::fabs(hi)) + 1e-6f;
+        return !(hi + slack < lo - slack);
+    }
+    bool Any(const Ray& ray, float kMin, float kMax) const {
+        for (const SceneObjectRef& s : always) if (s.h->FastTryHit(ray, kMin, kMax)) return true;
+        if (nodes.empty()) return false;
+        const V3 invD = v3(1.0f) / ray.d;
+        const float farSide = Distance(ray.o, centre) + radius;
+        const float reach = ((kMax < farSide) ? kMax : farSide) + (2.0f * maxObjectRadius);
+#ifndef ORC_CULL_PAD
+#define ORC_CULL_PAD 3e-3f
+#endif
+        const float pad = (ORC_CULL_PAD * reach) + 1e-4f;
+        uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+        while (sp) {
+            const Node& n = nodes[stack[--sp]];
+            if (!MayHit(n.box, ray, invD, kMin, kMax, pad)) continue;
+            if (n.count) { for (uint32_t i = 0; i < n.count; i++) if (order[n.first + i].h->FastTryHit(ray, kMin, kMax)) return true; }
+            else if (sp + 2 <= 128) { stack[sp++] = n.left; stack[sp++] = n.right; }
+        }
+        return false;
+    }
+};
+
 struct SceneData;
 static Colour TextureColour(const SceneData& sc, uint32_t tex, const HitRecord& hit);
 
@@ -732,6 +822,8 @@ struct SceneData {
     std::vector<rt_light> lights;
     std::unique_ptr<BvhNode> root;                        // over non-medium objects (D3)
     std::vector<SceneObjectRef> media;
+    CullTree cull;                                        // checker-only acceleration of AnyIntersectionFast (see CullTree)
+    bool culledAny = false;                               // orc_scene_set_culled_any: shadow rays of orc_render go through `cull`
 };
 
 static std::unique_ptr<Hittable> MakeHittable(const rt_scene_desc& d, uint32_t type, uint32_t index, std::string& err) {
@@ -784,11 +876,15 @@ static Found TryFindClosestHit(const SceneData& sc, const Ray& ray, float kMin, 
 }
 
 // RenderJob.AnyIntersectionFast, Core/RenderJob.cs:575 — a DFS over every leaf, no AABB culling.
-static bool AnyIntersectionFast(const SceneData& sc, const Ray& ray, float kMin, float kMax, Stats& st) {
-    st.shadowRays++;
+static bool ListAny(const SceneData& sc, const Ray& ray, float kMin, float kMax) {
     if (sc.root->FastTryHit(ray, kMin, kMax)) return true;
     for (const SceneObjectRef& m : sc.media) if (m.h->FastTryHit(ray, kMin, kMax)) return true;
     return false;
+}
+static bool AnyIntersectionFast(const SceneData& sc, const Ray& ray, float kMin, float kMax, Stats& st) {
+    st.shadowRays++;
+    if (sc.culledAny) return sc.cull.Any(ray, kMin, kMax);                                              // checker-only shortcut, proven equal by tests/
+    return ListAny(sc, ray, kMin, kMax);
 }
 
 static Colour TextureColour(const SceneData& sc, uint32_t tex, const HitRecord& hit) {
@@ -1165,6 +1261,7 @@ int orc_scene_create(const rt_scene_desc* d, orc_scene** out) {
         sc.lightShapes.push_back(std::move(shape));
     }
     sc.root = FromSegment_SAH(solids, 0);
+    sc.cull.Build(solids, sc.media);
     *out = s.release();
     return RT_OK;
 }
@@ -1191,14 +1288,35 @@ int orc_trace_closest(orc_scene* s, const rt_ray* rays, uint64_t n, float kMin, 
     return RT_OK;
 }
 
-int orc_trace_any(orc_scene* s, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
-    Stats st;
-    for (uint64_t i = 0; i < n; i++) {
-        Ray r = Ray::Raw(v3(rays[i].origin), v3(rays[i].direction));
-        occluded[i] = AnyIntersectionFast(s->sc, r, kMin[i], kMax[i], st) ? 1 : 0;
-    }
+// AnyIntersectionFast on caller-supplied rays.  culled = 0: the reference's scan of every object; 1: through CullTree.
+static int trace_any_impl(orc_scene* s, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded, bool culled, uint32_t n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+        Stats st;
+        for (;;) {
+            const uint64_t b = next.fetch_add(64);
+            if (b >= n) break;
+            for (uint64_t i = b; i < std::min(n, b + 64); i++) {
+                Ray r = Ray::Raw(v3(rays[i].origin), v3(rays[i].direction));
+                bool hit;
+                if (culled) hit = s->sc.cull.Any(r, kMin[i], kMax[i]);
+                else hit = ListAny(s->sc, r, kMin[i], kMax[i]);
+                occluded[i] = hit ? 1 : 0;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < n_threads; t++) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
     return RT_OK;
 }
+int orc_trace_any(orc_scene* s, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) { return trace_any_impl(s, rays, kMin, kMax, n, occluded, false, 1); }
+int orc_trace_any_mt(orc_scene* s, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded, uint32_t n_threads) { return trace_any_impl(s, rays, kMin, kMax, n, occluded, false, n_threads); }
+int orc_trace_any_culled(orc_scene* s, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded, uint32_t n_threads) { return trace_any_impl(s, rays, kMin, kMax, n, occluded, true, n_threads); }
+// orc_render's shadow rays through CullTree (1) or the reference's scan (0, the default)
+int orc_scene_set_culled_any(orc_scene* s, int enable) { s->sc.culledAny = enable != 0; return RT_OK; }
 
 // RenderJob.RenderInternal + UpdateBuffers' accumulation, Core/RenderJob.cs:69-126, 626-647.
 // rgb_sum is in image-row order (row 0 = top, the y-flip of :631) and is accumulated into.

@@ -8,7 +8,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")     # RT_HIP_LIB: A/B a differently built library
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
+RT_MAX_DEVICES = 16
+RENDER_EXACT_LIGHT_SAMPLING = 1
 RT_NO_HIT = 0xFFFFFFFF
 RT_DEPTH_HIST_SIZE = 64
 
@@ -108,7 +110,8 @@ class RenderOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("k_min", C.c_float), ("k_max", C.c_float),
                 ("max_bounce_depth", C.c_uint32), ("light_sample_count_hint", C.c_uint32), ("debug_visualisation", C.c_uint32),
                 ("seed", C.c_uint64), ("passes_per_batch", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
-                ("accum_device", C.c_void_p)]
+                ("accum_device", C.c_void_p), ("flags", C.c_uint32), ("max_passes_per_call", C.c_uint32), ("n_devices", C.c_uint32),
+                ("device_ids", C.c_int32 * RT_MAX_DEVICES)]
 
 
 class Stats(C.Structure):

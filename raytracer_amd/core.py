@@ -217,7 +217,7 @@ class GraphicsDebugVisualisation:
 class RenderOptions:
     def __init__(self, RenderWidth=1920, RenderHeight=1080, KMin=0.001, KMax=math.inf, ConcurrencyLevel=None, Passes=100,
                  InfinitePasses=False, MaxBounceDepth=10, DebugVisualisation=0, LightSampleCountHint=2,
-                 Seed=0x5EED, PassesPerBatch=0):
+                 Seed=0x5EED, PassesPerBatch=0, ExactLightSampling=False):
         if RenderWidth < 1:
             raise ArgumentOutOfRangeError("Image cannot have a width of less than 1 pixel")           # :52
         if RenderHeight < 1:
@@ -242,6 +242,8 @@ class RenderOptions:
         # not in the reference: key of the counter RNG that replaces the unseeded Random.Shared (Core/RandUtils.cs:17)
         self.Seed = int(Seed)
         self.PassesPerBatch = int(PassesPerBatch)
+        # not in the reference: light sampling in correctly rounded arithmetic (rt_hip.h RT_RENDER_EXACT_LIGHT_SAMPLING) instead of 1-ulp hardware forms
+        self.ExactLightSampling = bool(ExactLightSampling)
 
 
 @dataclass

@@ -118,6 +118,7 @@ struct SceneDev {
     const rt_material* materials;
     const rt_texture* textures;
     const rt_light* lights;      uint32_t n_lights;
+    float bounds_centre[3], bounds_radius, max_object_radius;    // sphere around every bounded object; largest half-diagonal of one object's box (any_pad)
     rt_camera camera;
     rt_skybox skybox;
     // small all-sphere scenes: a copy of the tree laid out for LDS (see LdsTree), null otherwise
@@ -153,20 +154,14 @@ RT_FN bool slab_hit(float entry, float exit_, float kMax) {
     return !(hi <= entry);
 }
 
-// Both boxes of one node at once.  Bit-identical to two slab() calls: the same subtract and multiply per plane (packed-f32,
-// v_pk_add_f32 / v_pk_mul_f32 on the A/B pair), the swap is a select on the sign of invD, and the reference's `?:` folds are
-// exactly maxNum / minNum chains (a NaN plane distance never replaces a bound), i.e. v_max3_f32 / v_min3_f32.
+// Both boxes of one node at once.  NodePlanes = the six planes of child boxes A and B in the order the ray meets them (per axis the
+// near plane is the box's min plane when the ray runs in +axis direction, its max plane otherwise: the reference's swap of t0 / t1
+// on invD < 0, done on the operands instead of on the products — the same subtract and the same multiply per plane, so the
+// distances are bit-identical to AxisAlignedBoundingBox.Hit).  The reference's `?:` folds are exactly maxNum / minNum chains (a NaN
+// plane distance never replaces a bound), i.e. v_max3_f32 / v_min3_f32; the A/B pair goes through packed-f32 instructions.
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct RaySigns { bool x, y, z; };
-RT_FN void slab_pair(float4 q0, float4 q1, float4 q2, f3 o, f3 invD, RaySigns neg, float kMin, float& enA, float& exA, float& enB, float& exB) {
-    v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {invD.x, invD.x}, iy = {invD.y, invD.y}, iz = {invD.z, invD.z};
-    v2f mnx = {q0.x, q0.y}, mny = {q0.z, q0.w}, mnz = {q1.x, q1.y}, mxx = {q1.z, q1.w}, mxy = {q2.x, q2.y}, mxz = {q2.z, q2.w};
-    v2f ax = (mnx - ox) * ix, bx = (mxx - ox) * ix;
-    v2f ay = (mny - oy) * iy, by = (mxy - oy) * iy;
-    v2f az = (mnz - oz) * iz, bz = (mxz - oz) * iz;
-    v2f nx = neg.x ? bx : ax, fx = neg.x ? ax : bx;
-    v2f ny = neg.y ? by : ay, fy = neg.y ? ay : by;
-    v2f nz = neg.z ? bz : az, fz = neg.z ? az : bz;
+struct NodePlanes { v2f nx, fx, ny, fy, nz, fz; };
+RT_FN void fold_planes(v2f nx, v2f fx, v2f ny, v2f fy, v2f nz, v2f fz, float kMin, float& enA, float& exA, float& enB, float& exB) {
     enA = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.x, kMin), ny.x), nz.x);
     enB = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx.y, kMin), ny.y), nz.y);
     exA = __builtin_fminf(__builtin_fminf(fx.x, fy.x), fz.x);
@@ -441,7 +436,56 @@ RT_FN bool try_medium(const SceneDev& sc, uint32_t midx, uint32_t self_obj, Ray 
 // whichever its implementation-defined tree visits last, Core/Acceleration/BinaryBvhNode.cs:28-30).
 // ------------------------------------------------------------------------------------------------
 struct Closest { float k; uint32_t obj; float aux; };
-struct TravCount { uint32_t nodes, prims; };
+// nodes / prims: box tests and primitive tests (V and T of SURVEY 8d).  box_miss / prim_hit: closest-hit traversal only, the
+// reference's AabbMisses (BinaryBvhNode.cs:18, SingleObjectBvhNode.cs:15) and HittableIntersections (SingleObjectBvhNode.cs:23);
+// HittableMisses (:28) = prims - prim_hit.  (FastTryHit keeps no counters in the reference.)
+struct TravCount { uint32_t nodes, prims, box_miss, prim_hit; };
+RT_FN TravCount trav_count_zero() { TravCount c; c.nodes = 0; c.prims = 0; c.box_miss = 0; c.prim_hit = 0; return c; }
+
+// Any-hit traversal culls by boxes, the reference's AnyIntersectionFast does not (BinaryBvhNode.cs:41 asks every object).  The
+// answers agree as long as no intersector accepts a point outside its object's box — true in exact arithmetic, not in binary32: a
+// sphere test at distance D from the ray origin carries an error of up to ~1e-6 D^2 in its discriminant (cancellation in
+// halfB^2 - a c), so a ray that passes the sphere at up to sqrt(r^2 + 1e-6 D^2) can be reported as a hit, 1e-3 D outside the box
+// (observed: shadow rays from ground points 2 000 units away in the Demo scene).  So any-hit tests every box grown by
+// pad = 1.1e-3 * D + 1e-5 (the sphere's worst case is sqrt(18 * 2^-24) D = 1.04e-3 D), D = the farthest the centre of an object
+// the ray can report may be: the ray's range, capped by the far side of the scene, plus twice the largest object's half-diagonal.  Growing a box by pad on every side = measuring its min planes from origin + pad and its max
+// planes from origin - pad, so the node test costs no extra instruction (AnyBox below).
+// A ray prepared for node box tests.  ClosestBox is the reference's arithmetic (AxisAlignedBoundingBox.Hit, operand for operand: a
+// leaf's box test decides whether its object is asked at all, so its bits matter).  AnyBox is the any-hit form: the boxes grown by
+// `pad`, and — no reference arithmetic to reproduce here, BinaryBvhNode.FastTryHit has no box test — one fused multiply-add per
+// plane, t = plane * inv + (-(origin -+ pad) * inv): 6 packed FMAs per node instead of 6 packed subtracts and 6 packed multiplies.
+// The FMA form places a plane with an absolute error of ~2^-23 |origin| (the rounding of the precomputed addend), which the
+// pad absorbs (any_box adds it); 1/d is clamped to +-1e30 so that an axis-parallel ray gives +-huge, not inf - inf = NaN.
+// o8x/y/z: 8 where the ray runs against the axis, else 0 — the byte offset that makes LdsTree's node layout hand out near/far planes.
+#ifndef RT_ANY_FMA
+#define RT_ANY_FMA 1
+#endif
+struct ClosestBox {
+    f3 o, inv; uint32_t o8x, o8y, o8z;
+    RT_FN void fold(const NodePlanes& p, float kMin, float& enA, float& exA, float& enB, float& exB) const {
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+        fold_planes((p.nx - ox) * ix, (p.fx - ox) * ix, (p.ny - oy) * iy, (p.fy - oy) * iy, (p.nz - oz) * iz, (p.fz - oz) * iz, kMin, enA, exA, enB, exB);
+    }
+};
+RT_FN ClosestBox closest_box(const Ray& r) {
+    ClosestBox b; b.o = r.o; b.inv = splat(1.0f) / r.d;
+    b.o8x = b.inv.x < 0.0f ? 8u : 0u; b.o8y = b.inv.y < 0.0f ? 8u : 0u; b.o8z = b.inv.z < 0.0f ? 8u : 0u;
+    return b;
+}
+struct AnyBox {
+    f3 inv, an, af; uint32_t o8x, o8y, o8z;      // an / af belong to the near / far plane of each axis: RT_ANY_FMA the addends, otherwise the shifted origins
+    RT_FN void fold(const NodePlanes& p, float kMin, float& enA, float& exA, float& enB, float& exB) const {
+        const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+        const v2f anx = {an.x, an.x}, any = {an.y, an.y}, anz = {an.z, an.z}, afx = {af.x, af.x}, afy = {af.y, af.y}, afz = {af.z, af.z};
+#if RT_ANY_FMA
+        fold_planes(__builtin_elementwise_fma(p.nx, ix, anx), __builtin_elementwise_fma(p.fx, ix, afx), __builtin_elementwise_fma(p.ny, iy, any),
+                    __builtin_elementwise_fma(p.fy, iy, afy), __builtin_elementwise_fma(p.nz, iz, anz), __builtin_elementwise_fma(p.fz, iz, afz), kMin, enA, exA, enB, exB);
+#else
+        fold_planes((p.nx - anx) * ix, (p.fx - afx) * ix, (p.ny - any) * iy, (p.fy - afy) * iy, (p.nz - anz) * iz, (p.fz - afz) * iz, kMin, enA, exA, enB, exB);
+#endif
+    }
+};
+RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax);
 
 RT_FN void consider(Closest& best, float k, uint32_t obj, float aux) {
     if (best.obj != RT_NO_HIT && k == best.k && best.obj > obj) return;
@@ -464,14 +508,23 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 #ifndef RT_LDS_VOTE
 #define RT_LDS_VOTE 0
 #endif
+// the 64-B node record (q0 q1 q2 of struct Node) -> near / far planes for this ray
+template <class Box>
+RT_FN void planes_of(float4 q0, float4 q1, float4 q2, const Box& box, NodePlanes& p) {
+    const bool gx = box.inv.x < 0.0f, gy = box.inv.y < 0.0f, gz = box.inv.z < 0.0f;
+    const v2f mnx = {q0.x, q0.y}, mny = {q0.z, q0.w}, mnz = {q1.x, q1.y}, mxx = {q1.z, q1.w}, mxy = {q2.x, q2.y}, mxz = {q2.z, q2.w};
+    p.nx = gx ? mxx : mnx; p.fx = gx ? mnx : mxx;
+    p.ny = gy ? mxy : mny; p.fy = gy ? mny : mxy;
+    p.nz = gz ? mxz : mnz; p.fz = gz ? mnz : mxz;
+}
 struct HbmTree {
     static constexpr bool vote = RT_TRAV_VOTE;
     static constexpr bool any_order = true;
     static constexpr bool list = true;       // scenes of a handful of objects are walked as a list (list_closest)
     int* stack; int stride;
-    RT_FN void node(const SceneDev& sc, int i, float4& q0, float4& q1, float4& q2, int2& ch) const {
+    template <class Box> RT_FN void planes(const SceneDev& sc, int i, const Box& box, NodePlanes& p, int2& ch) const {
         const Node* np = sc.nodes + i;
-        q0 = np->q0; q1 = np->q1; q2 = np->q2; ch = *(const int2*)&np->q3;
+        planes_of(np->q0, np->q1, np->q2, box, p); ch = *(const int2*)&np->q3;
     }
     RT_FN void push(int sp, int v) const { stack[sp * stride] = v; }
     RT_FN int pop(int sp) const { return stack[sp * stride]; }
@@ -490,25 +543,37 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
     uint32_t code = leaf_code(sc, obj);
     return fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
 }
+// LDS image (built by rt_scene_create): n_nodes records of LDS_NODE_BYTES, then the sphere table (float4 per object id).
+//   node record: per axis x, y, z 24 B = (min A, min B, max A, max B, min A, min B), then (child A, child B).
+// The repeated min pair makes the ray's sign a byte offset instead of twelve selects: at +0 the lane reads (min pair, max pair) =
+// (near, far) for a ray along +axis, at +8 it reads (max pair, min pair) = (near, far) for a ray along -axis — one ds_read2_b64 per
+// axis.  The stack column holds 16-bit entries: an inner node index (< 32768) as it is, a leaf ~object as the negative number it is
+// (ds_read_i16 sign-extends it back), so push and pop are one LDS instruction each, no encoding.
+constexpr uint32_t LDS_NODE_BYTES = 80;
 struct LdsTree {
     static constexpr bool any_order = false;
     static constexpr bool list = false;      // (the host never pairs the LDS tree with an object list: keeps these kernels' registers)
     static constexpr bool vote = RT_LDS_VOTE;      // rays of equal cost: the votes only cost instructions here
-    const float4* q0; const float4* q1; const float4* q2; const int2* ch; const float4* sph;
-    unsigned short* stack; int stride;
-    RT_FN void node(const SceneDev&, int i, float4& a, float4& b, float4& c, int2& d) const { a = q0[i]; b = q1[i]; c = q2[i]; d = ch[i]; }
-    RT_FN void push(int sp, int v) const { stack[sp * stride] = (unsigned short)(v >= 0 ? v : (0x8000 | ~v)); }
-    RT_FN int pop(int sp) const { int e = stack[sp * stride]; return (e & 0x8000) ? ~(e & 0x7FFF) : e; }
+    const char* nodes; const float4* sph;
+    short* stack; int stride;
+    template <class Box> RT_FN void planes(const SceneDev&, int i, const Box& box, NodePlanes& p, int2& ch) const {
+        const char* n = nodes + (uint32_t)i * LDS_NODE_BYTES;
+        const char* ax = n + box.o8x; const char* ay = n + 24 + box.o8y; const char* az = n + 48 + box.o8z;
+        p.nx = *(const v2f*)ax; p.fx = *(const v2f*)(ax + 8);
+        p.ny = *(const v2f*)ay; p.fy = *(const v2f*)(ay + 8);
+        p.nz = *(const v2f*)az; p.fz = *(const v2f*)(az + 8);
+        ch = *(const int2*)(n + 72);
+    }
+    RT_FN void push(int sp, int v) const { stack[sp * stride] = (short)v; }
+    RT_FN int pop(int sp) const { return (int)stack[sp * stride]; }
     template <class C> RT_FN bool leaf_try(const SceneDev&, uint32_t obj, Ray r, float kMin, float kMax, float& k) const { return try_sphere(sph[obj], r, kMin, kMax, k); }
     template <class C> RT_FN bool leaf_fast(const SceneDev&, uint32_t obj, Ray r, float kMin, float kMax) const { float k; return try_sphere(sph[obj], r, kMin, kMax, k); }
     // carve the LDS image (copied verbatim from SceneDev::lds_image) into its tables
     RT_FN static LdsTree carve(const void* base, uint32_t n_nodes, uint32_t n_objects, uint32_t image_bytes, int tid, int block) {
         LdsTree t;
-        const float4* f = (const float4*)base;
-        t.q0 = f; t.q1 = f + n_nodes; t.q2 = f + 2 * (size_t)n_nodes;
-        t.ch = (const int2*)(f + 3 * (size_t)n_nodes);
-        t.sph = f + 3 * (size_t)n_nodes + ((size_t)n_nodes + 1) / 2;
-        t.stack = (unsigned short*)((const char*)base + image_bytes) + tid; t.stride = block;
+        t.nodes = (const char*)base;
+        t.sph = (const float4*)((const char*)base + (size_t)n_nodes * LDS_NODE_BYTES);
+        t.stack = (short*)((const char*)base + image_bytes) + tid; t.stride = block;
         (void)n_objects;
         return t;
     }
@@ -523,21 +588,21 @@ struct LdsTree {
 // One inner-node step: test both child boxes against [kMin, kMax] (kMax = the best K so far for closest hit), continue with
 // the nearer hit child, push the other, pop when neither is hit; a leaf met while no leaf is parked is parked in `pend` and
 // the descent goes on.  ANY = any-hit rule: closed box interval, no near/far ordering.
-template <bool ANY, class Tree>
-RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Ray& r, f3 invD, float kMin, float kMax, int& cur, int& pend, int& sp) {
-    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
-    float4 q0, q1, q2; int2 ch;
-    tree.node(sc, cur, q0, q1, q2, ch);
+template <bool ANY, class Tree, class Box>
+RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Box& box, float kMin, float kMax, int& cur, int& pend, int& sp, uint32_t& box_miss) {
+    NodePlanes pl; int2 ch;
+    tree.planes(sc, cur, box, pl, ch);
     float enA, exA, enB, exB;
-    slab_pair(q0, q1, q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+    box.fold(pl, kMin, enA, exA, enB, exB);
     bool hA, hB;
-    if (ANY) {     // a hit exactly on a box face must never be culled: exit >= entry
-        const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;
+    if (ANY) {     // a hit exactly on a (grown) box face must never be culled: exit >= entry
+        const float hiA = __builtin_fminf(exA, kMax), hiB = __builtin_fminf(exB, kMax);
         hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
         hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
     } else {
         hA = (ch.x != CHILD_EMPTY) && slab_hit(enA, exA, kMax);
         hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, kMax);
+        box_miss += (hA ? 0u : 1u) + (hB ? 0u : 1u);
     }
     int next = ch.x; bool pop = false;
     if (hA && hB) {
@@ -589,38 +654,37 @@ RT_FN bool step_vote(int cur, int pend) {
 // batch (513 -> 732 Msamples/s).  RT_HIP_LIST=<max objects> (default 16, 0 = never) is the A/B knob.
 template <class C>
 RT_FN void list_closest(const SceneDev& sc, const Ray& r, float kMin, Closest& best, TravCount& cnt) {
-    const f3 invD = splat(1.0f) / r.d;
-    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
+    const ClosestBox box = closest_box(r);
     for (uint32_t p = 0; p < sc.n_list_pairs; p++) {
         const Node* np = sc.list + p;
-        float enA, exA, enB, exB;
-        slab_pair(np->q0, np->q1, np->q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+        float enA, exA, enB, exB; NodePlanes pl;
+        planes_of(np->q0, np->q1, np->q2, box, pl);
+        box.fold(pl, kMin, enA, exA, enB, exB);
         const int cA = np->q3.x, cB = np->q3.y;
         cnt.nodes += 2;
         if (slab_hit(enA, exA, best.k)) {
             const uint32_t obj = (uint32_t)~cA, code = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.obj_code[obj]);
             float k; cnt.prims++;
-            if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
-        }
+            if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
+        } else cnt.box_miss++;
         if (cB != CHILD_EMPTY && slab_hit(enB, exB, best.k)) {
             const uint32_t obj = (uint32_t)~cB, code = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.obj_code[obj]);
             float k; cnt.prims++;
-            if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
-        }
+            if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
+        } else cnt.box_miss++;
     }
 }
 template <class C>
-RT_FN bool list_any(const SceneDev& sc, const Ray& r, float kMin, float kMax, TravCount& cnt) {
-    const f3 invD = splat(1.0f) / r.d;
-    RaySigns neg; neg.x = invD.x < 0.0f; neg.y = invD.y < 0.0f; neg.z = invD.z < 0.0f;
+RT_FN bool list_any(const SceneDev& sc, const Ray& r, const AnyBox& box, float kMin, float kMax, TravCount& cnt) {
     bool occluded = false;
     for (uint32_t p = 0; p < sc.n_list_pairs; p++) {
         if (!__any(!occluded)) break;
         const Node* np = sc.list + p;
-        float enA, exA, enB, exB;
-        slab_pair(np->q0, np->q1, np->q2, r.o, invD, neg, kMin, enA, exA, enB, exB);
+        float enA, exA, enB, exB; NodePlanes pl;
+        planes_of(np->q0, np->q1, np->q2, box, pl);
+        box.fold(pl, kMin, enA, exA, enB, exB);
         const int cA = np->q3.x, cB = np->q3.y;
-        const float hiA = exA < kMax ? exA : kMax, hiB = exB < kMax ? exB : kMax;      // closed interval: a hit on a box face is never culled
+        const float hiA = __builtin_fminf(exA, kMax), hiB = __builtin_fminf(exB, kMax);      // closed interval: a hit on a box face is never culled
         if (!occluded) cnt.nodes += 2;
         if (!occluded && !(hiA < enA)) {
             const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.obj_code[(uint32_t)~cA]);
@@ -636,6 +700,36 @@ RT_FN bool list_any(const SceneDev& sc, const Ray& r, float kMin, float kMax, Tr
     return occluded;
 }
 
+RT_FN float rcp_fast(float a);
+RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax) {
+    const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
+    const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;      // no bounded object is farther from the origin
+    const float reach = (kMax < far_side ? kMax : far_side) + (2.0f * sc.max_object_radius);     // (a NaN kMax leaves far_side)
+    float pad = (1.1e-3f * reach) + 1e-5f;
+    AnyBox b;
+#if RT_ANY_FMA
+    f3 inv = mk3(rcp_fast(r.d.x), rcp_fast(r.d.y), rcp_fast(r.d.z));      // 1 ulp is plenty for boxes grown by pad (a correctly rounded divide is 11 instructions)
+#else
+    f3 inv = splat(1.0f) / r.d;
+#endif
+#if RT_ANY_FMA
+    pad = pad + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)));
+    inv = mk3(__builtin_fminf(__builtin_fmaxf(inv.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(inv.y, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(inv.z, -1e30f), 1e30f));
+#endif
+    b.inv = inv;
+    const bool gx = inv.x < 0.0f, gy = inv.y < 0.0f, gz = inv.z < 0.0f;
+    b.o8x = gx ? 8u : 0u; b.o8y = gy ? 8u : 0u; b.o8z = gz ? 8u : 0u;
+    // the box grown by pad: its min planes move by -pad, its max planes by +pad; the near plane is the min plane unless the ray runs against the axis
+    const f3 on = mk3(gx ? r.o.x - pad : r.o.x + pad, gy ? r.o.y - pad : r.o.y + pad, gz ? r.o.z - pad : r.o.z + pad);
+    const f3 of = mk3(gx ? r.o.x + pad : r.o.x - pad, gy ? r.o.y + pad : r.o.y - pad, gz ? r.o.z + pad : r.o.z - pad);
+#if RT_ANY_FMA
+    b.an = -on * inv; b.af = -of * inv;
+#else
+    b.an = on; b.af = of;
+#endif
+    return b;
+}
+
 template <class C, class Tree>
 RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
@@ -643,18 +737,18 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
         uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
         float k; cnt.prims++;
-        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
     }
     if (Tree::list && sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
     else if (sc.n_nodes) {
-        const f3 invD = splat(1.0f) / r.d;
+        const ClosestBox box = closest_box(r);
         int sp = 0, cur = 0, pend = TRAV_DONE;
         for (;;) {
-            if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); } }
-            else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }   // every lane does box tests here
+            if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); } }
+            else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); }   // every lane does box tests here
             if (pend != TRAV_DONE) {                               // leaves: most lanes arrive here with one parked
                 uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
-                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
             }
             if (cur == TRAV_DONE) break;
             leaf_advance(tree, cur, pend, sp);
@@ -666,7 +760,7 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
             float k, aux; cnt.prims++;
             // SingleObjectBvhNode box test (the medium's BoundingVolume is its boundary's, ConstantDensityMedium.cs:80) is implied:
             // the boundary intersector only returns points inside that box.
-            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) { consider(best, k, obj, aux); cnt.prim_hit++; }
         }
     }
     // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
@@ -688,13 +782,14 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
             if (fast_object_solid<C>(sc, m.boundary_type, m.boundary_index, r, kMin, kMax)) return true;      // ConstantDensityMedium.cs:77
         }
     }
-    if (Tree::list && sc.n_list_pairs) return list_any<C>(sc, r, kMin, kMax, cnt);
-    if (!sc.n_nodes) return false;
-    const f3 invD = splat(1.0f) / r.d;
+    if (!(Tree::list && sc.n_list_pairs) && !sc.n_nodes) return false;
+    const AnyBox box = any_box(sc, r, kMax);
+    if (Tree::list && sc.n_list_pairs) return list_any<C>(sc, r, box, kMin, kMax, cnt);
     int sp = 0, cur = 0, pend = TRAV_DONE;
+    uint32_t unused = 0;
     for (;;) {
-        if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); } }
-        else while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
+        if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); } }
+        else while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
         if (pend != TRAV_DONE) {
             cnt.prims++;
             if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) return true;
@@ -916,42 +1011,65 @@ RT_FN col3 sky_colour(const SceneDev& sc, f3 dir) {
 // ------------------------------------------------------------------------------------------------
 struct ShadowRay { Ray r; float kMin, kMax; };
 
-// Light sampling arithmetic.  Traversal and the intersectors are correctly rounded (they decide hit ids and K, which the parity
-// check compares bit for bit); what PRODUCES a shadow ray and weights its light is sampling arithmetic whose last bit only moves a
-// sample by an ulp, so it uses the hardware's 1-ulp v_rsq_f32 / v_sqrt_f32 / v_rcp_f32 / v_exp_f32 instead of the ~12-instruction
-// correctly rounded sequences (a normalise is 4 instructions instead of 45).  Images stay inside the stated tolerance (tests).
+// Light sampling arithmetic, two modes (template parameter EXACT of the shadow kernels; rt_render_opts.flags / RT_HIP_EXACT_LIGHTS):
+//   EXACT = false (default): traversal and the intersectors are correctly rounded (they decide hit ids and K, which the parity
+//     check compares bit for bit); what PRODUCES a shadow ray and weights its light is sampling arithmetic whose last bit only
+//     moves a sample by an ulp, so it uses the hardware's 1-ulp v_rsq_f32 / v_sqrt_f32 / v_rcp_f32 / v_exp_f32 instead of the
+//     ~12-instruction correctly rounded sequences (a normalise is 4 instructions instead of 45).  A shadow ray that grazes an
+//     occluder within that ulp may fall the other way: the image then differs from the reference arithmetic by one light sample
+//     in a few pixels per thousand (tests bound it).
+//   EXACT = true: every operator as the reference writes it (Normalize = v / Sqrt(Dot), Distance, x / AttenuationRadius,
+//     MathF.Pow(MathF.E, y), sum / samples), correctly rounded: the shadow rays are bit-identical to the CPU restatement's.
 RT_FN f3 normalize_fast(f3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
 RT_FN float length_fast(f3 a) { return __builtin_amdgcn_sqrtf(dot(a, a)); }
 RT_FN float rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
 RT_FN float exp_e_fast(float y) { return __builtin_amdgcn_exp2f(y * 1.44269502f); }     // MathF.Pow(MathF.E, y): log2((float)e) rounds to the same float as log2(e)
+template <bool EXACT> RT_FN float exp_e(float y) { if constexpr (EXACT) return powf(E_F, y); else return exp_e_fast(y); }
+template <bool EXACT> RT_FN float div_by(float a, float b) { if constexpr (EXACT) return a / b; else return a * rcp_fast(b); }
 
-RT_FN ShadowRay default_shadow_ray(f3 hitPos, f3 lightPos) {                             // SimpleLightBase.cs:42-51
-    f3 v = lightPos - hitPos;
-    float d2 = dot(v, v), inv = __builtin_amdgcn_rsqf(d2);
-    ShadowRay s; s.r.o = hitPos; s.r.d = v * inv;                                        // Ray.FromPoints -> ctor normalises
-    s.kMin = 0.01f; s.kMax = (d2 * inv) - 0.01f;                                         // Vector3.Distance
+template <bool EXACT>
+RT_FN ShadowRay default_shadow_ray(f3 hitPos, f3 lightPos) {                             // SimpleLightBase.DefaultGetShadowRayForHit, SimpleLightBase.cs:68-77
+    ShadowRay s; s.r.o = hitPos; s.kMin = 0.01f;
+    if constexpr (EXACT) {
+        s.r.d = normalize(lightPos - hitPos);                                            // Ray.FromPoints -> the Ray ctor normalises (Core/Ray.cs:17,26)
+        s.kMax = distance(hitPos, lightPos) - 0.01f;                                     // Vector3.Distance(hitPos, lightPos) - kMin
+    } else {
+        f3 v = lightPos - hitPos;
+        float d2 = dot(v, v), inv = __builtin_amdgcn_rsqf(d2);
+        s.r.d = v * inv;
+        s.kMax = (d2 * inv) - 0.01f;
+    }
     return s;
 }
-RT_FN float attenuation(const rt_light* l, float x) {                                    // SimpleLightBase.cs:55-77
+template <bool EXACT>
+RT_FN float attenuation(const rt_light* l, float x) {                                    // the DistanceAttenuation factories, SimpleLightBase.cs:83-132
     switch (l->atten_kind) {
         case RT_ATTEN_CONSTANT: return l->atten_p[0];
         case RT_ATTEN_LINEAR: return 1 - x;
         case RT_ATTEN_POWER: return powf(1 - x, l->atten_p[0]);
         case RT_ATTEN_POWER_STAY_HIGH: return 1 - powf(x, l->atten_p[0]);
-        case RT_ATTEN_LOGISTIC: return rcp_fast(1 + exp_e_fast(l->atten_p[1] * (x - l->atten_p[0])));
-        case RT_ATTEN_LOGISTIC_LKX: return l->atten_p[0] * rcp_fast(1.0f + exp_e_fast(-l->atten_p[1] * (x - l->atten_p[2])));
-        default: return exp_e_fast(l->atten_p[0] * -x);
+        case RT_ATTEN_LOGISTIC: return div_by<EXACT>(1.0f, 1 + exp_e<EXACT>(l->atten_p[1] * (x - l->atten_p[0])));
+        case RT_ATTEN_LOGISTIC_LKX: return div_by<EXACT>(l->atten_p[0], 1.0f + exp_e<EXACT>(-l->atten_p[1] * (x - l->atten_p[2])));
+        default: return exp_e<EXACT>(l->atten_p[0] * -x);
     }
 }
-// GetShadowRayForHit: PointLight.cs:7, DiffuseSphereLight.cs:85-139, DiffuseShapedLight.cs:67-103
-template <class C>
+// SimpleLightBase.CalculateLight after the occlusion test, SimpleLightBase.cs:57-65: cutoff, attenuation of kMax / AttenuationRadius, clamp at 0
+template <bool EXACT>
+RT_FN col3 light_contribution(const rt_light* l, float kMax) {
+    if (kMax > l->cutoff_radius) return mkc(0, 0, 0);
+    float scale = attenuation<EXACT>(l, div_by<EXACT>(kMax, l->attenuation_radius));
+    scale = maxf_net(scale, 0);
+    return mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
+}
+// GetShadowRayForHit: PointLight.cs:9, DiffuseSphereLight.cs:88-142, DiffuseShapedLight.cs:69-105
+template <class C, bool EXACT>
 RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f3 normal, const RngKey& key, uint32_t depth, uint32_t slotBase, uint32_t sub) {
     f3 pos = mk3(l->position[0], l->position[1], l->position[2]);
     // (the host picks a kernel variant whose Cfg covers every light type in the scene, so a type outside C::lights cannot occur)
-    if (l->type == RT_LIGHT_POINT || C::lights == (1u << RT_LIGHT_POINT)) return default_shadow_ray(wp, pos);
+    if (l->type == RT_LIGHT_POINT || C::lights == (1u << RT_LIGHT_POINT)) return default_shadow_ray<EXACT>(wp, pos);
     if (RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SPHERE) && (l->type == RT_LIGHT_DIFFUSE_SPHERE || !RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SHAPED))) {
         float R = l->diffusion_radius;
-        if (length_fast(wp - pos) <= R * 1.01f) {
+        if ((EXACT ? distance(wp, pos) : length_fast(wp - pos)) <= R * 1.01f) {
             for (uint32_t i = 0; i < 1000; i++) {
                 float4 u = rng_draw(key, depth, slotBase + i, sub);
                 f3 randDir = on_unit_sphere(u.x, u.y, u.z);
@@ -965,18 +1083,24 @@ RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f
                 float sqrtD = sqrtf(disc);
                 float k = (-halfB - sqrtD) / a;
                 if (is_nan(k)) { k = (-halfB + sqrtD) / a; if (is_nan(k)) continue; }
-                ShadowRay s; s.r.o = wp; s.r.d = normalize_fast(randDir); s.kMin = 0.001f; s.kMax = k;
+                ShadowRay s; s.r.o = wp; s.r.d = EXACT ? normalize(randDir) : normalize_fast(randDir); s.kMin = 0.001f; s.kMax = k;   // new Ray(hit, randDir) normalises
                 return s;
             }
-            return default_shadow_ray(wp, pos);
+            return default_shadow_ray<EXACT>(wp, pos);
         }
         float4 u = rng_draw(key, depth, slotBase, sub);
-        f3 randDir = normalize_fast(mk3(plus_minus_one(u.x), plus_minus_one(u.y), plus_minus_one(u.z)));      // RandomOnUnitSphere
-        if (dot(randDir, wp - pos) < 0) randDir = -randDir;                              // sign of dot(randDir, Normalize(hit - centre))
-        return default_shadow_ray(wp, pos + (randDir * R));
+        f3 randDir;
+        if constexpr (EXACT) {
+            randDir = on_unit_sphere(u.x, u.y, u.z);                                     // RandomOnUnitSphere
+            if (dot(randDir, normalize(wp - pos)) < 0) randDir = -randDir;               // DiffuseSphereLight.cs: Dot(randDir, Normalize(hit - centre))
+        } else {
+            randDir = normalize_fast(mk3(plus_minus_one(u.x), plus_minus_one(u.y), plus_minus_one(u.z)));
+            if (dot(randDir, wp - pos) < 0) randDir = -randDir;                          // the sign of the same dot product
+        }
+        return default_shadow_ray<EXACT>(wp, pos + (randDir * R));
     }
     // DiffuseShapedLight
-    if constexpr (!RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SHAPED)) return default_shadow_ray(wp, pos);
+    if constexpr (!RT_HAS_LIGHT(C, RT_LIGHT_DIFFUSE_SHAPED)) return default_shadow_ray<EXACT>(wp, pos);
     f3 mn = mk3(l->shape_aabb_min[0], l->shape_aabb_min[1], l->shape_aabb_min[2]), mx = mk3(l->shape_aabb_max[0], l->shape_aabb_max[1], l->shape_aabb_max[2]);
     for (uint32_t i = 0; i < 1000; i++) {
         float4 u = rng_draw(key, depth, slotBase + i, sub);

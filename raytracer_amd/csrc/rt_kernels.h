@@ -23,6 +23,7 @@ constexpr int BLOCK = 256;
 
 enum StatSlot : int {
     ST_RAYS = 0, ST_SHADOW_RAYS, ST_NODES, ST_PRIMS, ST_SH_NODES, ST_SH_PRIMS, ST_SKY, ST_LIMIT, ST_SCATTER, ST_ABSORBED, ST_SAMPLES,
+    ST_BOX_MISS, ST_PRIM_HIT,        // AabbMisses, HittableIntersections (HittableMisses = ST_PRIMS - ST_PRIM_HIT)
     ST_DEPTH0, ST_COUNT = ST_DEPTH0 + RT_DEPTH_HIST_SIZE
 };
 
@@ -74,18 +75,22 @@ RT_FN void stat_add_block(unsigned long long* stats, const int (&slot)[N], const
 #pragma unroll
     for (int i = 0; i < N; i++) { const unsigned long long w = wave_sum(v[i]); if (lane_id() == 0) red[i][wave] = w; }
     __syncthreads();
-    if (threadIdx.x < N) {
-        unsigned long long t = 0;
-        for (uint32_t w = 0; w < n_waves; w++) t += red[threadIdx.x][w];
-        int sl = slot[0];
+    // thread i adds counter i: every index below is a compile-time constant, so slot[] and v[] stay in registers
 #pragma unroll
-        for (int i = 1; i < N; i++) if ((int)threadIdx.x == i) sl = slot[i];
-        if (t) atomicAdd(stats + sl, t);
-    }
+    for (int i = 0; i < N; i++)
+        if ((int)threadIdx.x == i) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < n_waves; w++) t += red[i][w];
+            if (t) atomicAdd(stats + slot[i], t);
+        }
 }
 RT_FN void stat_add3_block(unsigned long long* stats, int s0, int s1, int s2, uint32_t v0, uint32_t v1, uint32_t v2) {
     const int slot[3] = {s0, s1, s2}; const unsigned long long v[3] = {v0, v1, v2};
     stat_add_block<3>(stats, slot, v);
+}
+RT_FN void stat_add_closest(unsigned long long* stats, uint32_t rays, const TravCount& c) {
+    const int slot[5] = {ST_RAYS, ST_NODES, ST_PRIMS, ST_BOX_MISS, ST_PRIM_HIT}; const unsigned long long v[5] = {rays, c.nodes, c.prims, c.box_miss, c.prim_hit};
+    stat_add_block<5>(stats, slot, v);
 }
 
 RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
@@ -93,6 +98,7 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
     return make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
 }
 
+#ifdef RT_KERNELS_COMMON      // the kernels that do not depend on the scene variant: defined by rt_lib.hip only
 // RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay
 __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
     for (uint32_t id = blockIdx.x * BLOCK + threadIdx.x; id < rd.n_paths; id += gridDim.x * BLOCK) {
@@ -111,6 +117,8 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = rd.n_paths;
 }
+
+#endif
 
 extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsTree: scene image, then ushort [stack_depth][block]
 
@@ -138,19 +146,19 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
-    uint32_t rays = 0, nodes = 0, prims = 0;
+    uint32_t rays = 0;
+    TravCount cnt = trav_count_zero();
     for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
         float4 a = g0[j], b = g1[j];
         Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
         RngKey key = make_key(0, 0, 0);
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, g3[j].x);     // only a medium draws random numbers
-        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         Closest c = closest_hit<C>(sc, tree, r, rd.k_min, rd.k_max, key, depth, cnt);
         rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
-        rays++; nodes += cnt.nodes; prims += cnt.prims;
+        rays++;
     }
-    stat_add3_block(rd.stats, ST_RAYS, ST_NODES, ST_PRIMS, rays, nodes, prims);
+    stat_add_closest(rd.stats, rays, cnt);
 }
 
 // Persistent-lane closest hit.  In scenes where the cost of a ray has a heavy tail (a bounce ray skimming a 5 M-triangle terrain
@@ -185,10 +193,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     const uint32_t end = min(n, next + per_wave);
     const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
     uint32_t my_j = 0;
-    uint32_t rays = 0, nodes = 0, prims = 0;
+    uint32_t rays = 0;
+    TravCount cnt = trav_count_zero();
     bool active = false;                 // this lane holds a ray (possibly finished and waiting for its store)
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-    f3 invD = mk3(0, 0, 0);
+    ClosestBox box = closest_box(r);
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
     int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
     for (;;) {
@@ -201,8 +210,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                         RngKey key = path_key(rd, g3[my_j].x);        // only a medium draws random numbers
                         for (uint32_t i = 0; i < sc.n_media; i++) {
                             uint32_t obj = sc.media[i], code = sc.obj_code[obj];
-                            float k, aux; prims++;
-                            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) consider(best, k, obj, aux);
+                            float k, aux; cnt.prims++;
+                            if (try_medium<C>(sc, code & OBJ_INDEX_MASK, obj, r, kMin, best.k, key, depth, k, aux)) { consider(best, k, obj, aux); cnt.prim_hit++; }
                         }
                     }
                     rd.hit_aux[my_j] = best.aux;
@@ -222,10 +231,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 if (!ray_has_nan(r)) {
                     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
                         uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
-                        float k; prims++;
-                        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                        float k; cnt.prims++;
+                        if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
                     }
-                    if (sc.n_nodes) { invD = splat(1.0f) / r.d; cur = 0; }
+                    if (sc.n_nodes) { box = closest_box(r); cur = 0; }
                 }
             }
         }
@@ -236,11 +245,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
         }
         // ---- traverse until too few lanes are busy
         for (;;) {
-            if constexpr (decltype(tree)::vote) { while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); } }
-            else while (cur >= 0) { nodes += 2; node_step<false>(sc, tree, r, invD, kMin, best.k, cur, pend, sp); }
+            if constexpr (decltype(tree)::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); } }
+            else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); }
             if (pend != TRAV_DONE) {
-                uint32_t obj = (uint32_t)~pend; float k; prims++;
-                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) consider(best, k, obj, 0.0f);
+                uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
+                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
                 leaf_advance(tree, cur, pend, sp);
             }
             const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
             if (n_busy < REFILL_BELOW && next < end && 64 - n_busy >= REFILL_MIN_TAKERS) break;
         }
     }
-    stat_add3_block(rd.stats, ST_RAYS, ST_NODES, ST_PRIMS, rays, nodes, prims);
+    stat_add_closest(rd.stats, rays, cnt);
 }
 
 // Output positions.  A same-address returning atomic is serviced about every 10 ns chip-wide, so a reservation per wave
@@ -274,6 +283,9 @@ RT_FN col3 bounce_depth_colour(int maxDepthReached, uint32_t maxAllowedDepth) {
     float val = 1 - powf(E_F, -((float)(maxDepthReached * maxDepthReached) * sqrtf((float)maxAllowedDepth)));
     return (mkc(1, 1, 1) * (1.0f - val)) + ((mkc(0, 0, 1) * 0.02f) * val);
 }
+
+// `sum / samples` of Material.CalculateSimpleColourFromLights (Material.cs:43): Colour / float divides every channel
+template <bool EXACT> RT_FN col3 over_samples(col3 sum, float S) { if constexpr (EXACT) return sum / S; else return sum * rcp_fast(S); }
 
 // VIS = RenderOptions.DebugVisualisation != None (RenderJob.cs:148-309): the same kernel decides a debug colour from the first hit
 // instead of shading it (the host runs one bounce then, except for BounceDepth which runs the whole loop without colours).
@@ -335,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
             col3 L = mkc(a2.y, a2.z, a2.w);
             const uint32_t id = a3.x;
             Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
-            if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) c.aux = rd.hit_aux[j];
+            if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) { if (rd.hit_aux) c.aux = rd.hit_aux[j]; }      // (the debug-visualisation kernel is the generic one on every scene; a render of a scene without media has no hit_aux)
             if (c.obj == RT_NO_HIT) {                                                    // RenderJob.cs:444-450
                 if constexpr (VIS) { L = rd.vis == RT_VIS_BOUNCE_DEPTH ? bounce_depth_colour((int)depth - 1, rd.max_depth) : mkc(0, 0, 0); }   // NoColour / :303-305
                 else L = L + (T * sky_colour(sc, r.d));
@@ -456,13 +468,20 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     }
 }
 
-// Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:22-40)
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+// Material.CalculateSimpleColourFromLights (Material.cs:30-45) -> SimpleLightBase.CalculateLight (SimpleLightBase.cs:48-66).
+// EXACT: light sampling in the reference's correctly rounded arithmetic instead of the 1-ulp hardware forms (rt_device.h).
+// waves per SIMD the LDS-tree shadow kernel is held to.  6 (80 VGPRs) spills 15 registers around the traversal, 7 more: measured on
+// Night Spheres 1080p per 256-pass step 5 waves 74.5 ms, 6 waves 80.7 ms, 7 waves 87.2 ms (profiles/r02_d_ab.log)
+#ifndef RT_SHADOW_LDS_WAVES
+#define RT_SHADOW_LDS_WAVES 5
+#endif
+template <class C, bool LDS, bool EXACT = false>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS && !EXACT ? RT_SHADOW_LDS_WAVES : 1) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
-    uint32_t rays = 0, nodes = 0, prims = 0;          // per thread: at most a few thousand requests x rays x nodes
+    uint32_t rays = 0;                                // per thread: at most a few thousand requests x rays x nodes
+    TravCount cnt = trav_count_zero();
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     for (uint32_t p = blockIdx.x * TB + threadIdx.x; p < n; p += gridDim.x * TB) {
         float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
@@ -478,25 +497,18 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k
             phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;      // EstimatedLight is the plain light sum whatever the material (RenderJob.cs:234-250)
             if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
         }
-        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
         col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0);
         for (uint32_t s = 0; s < rd.light_samples; s++) {
             for (uint32_t li = 0; li < sc.n_lights; li++) {
                 const rt_light* l = sc.lights + li;
                 uint32_t sub = s * sc.n_lights + li;
-                ShadowRay sr = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
+                ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
                 rays++;
                 col3 c = mkc(0, 0, 0);
-                if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) {
-                    if (!(sr.kMax > l->cutoff_radius)) {
-                        float scale = attenuation(l, sr.kMax * rcp_fast(l->attenuation_radius));
-                        scale = maxf_net(scale, 0);
-                        c = mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
-                    }
-                }
+                if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
                 if (!phong) sum = sum + c;
                 else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:42-56
-                    ShadowRay s2 = light_shadow_ray<C>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
+                    ShadowRay s2 = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
                     col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
                     f3 rl = reflect(s2.r.d, -nrm);
@@ -507,21 +519,20 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k
                 }
             }
         }
-        float S = (float)rd.light_samples, invS = rcp_fast(S);
-        sum = sum * invS;
+        const float S = (float)rd.light_samples;
+        sum = over_samples<EXACT>(sum, S);
         const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
         const col3 W = mkc(e1.z, e1.w, e2.x);
         const uint32_t dst = __float_as_uint(e2.z);
         col3 add;
         if (!phong) add = W * sum;
-        else { spec_sum = spec_sum * invS; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
+        else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
         float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
         float4 t = *tgt;
         if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
         *tgt = t;
-        nodes += cnt.nodes; prims += cnt.prims;
     }
-    stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, nodes, prims);
+    stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, cnt.nodes, cnt.prims);
 }
 
 // Persistent-lane k_shadow (same reasoning as k_closest_persistent).  A request's rays are traced one after the other by its
@@ -532,8 +543,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS ? 6 : 1) k
 // waves per SIMD the kernel is held to, per variant (specialised next to the variants: 96 VGPRs instead of 99 for "spheres" is
 // 5 waves instead of 4 and 33.5 -> 36.8 Msamples/s on the 100 k spheres + 64 lights scene; the others would only spill)
 template <class C> struct ShadowPersistentTune { static constexpr int min_waves = 1; };
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, bool LDS, bool EXACT = false>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
@@ -553,7 +564,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
     const rt_material* m = nullptr; bool phong = false;
     col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0);
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-    f3 invD = mk3(0, 0, 0);
+    AnyBox box; box.inv = mk3(0, 0, 0); box.an = r.o; box.af = r.o; box.o8x = 0; box.o8y = 0; box.o8z = 0;
+    uint32_t unused = 0;
     float kMin = 0, kMax = 0;
     int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
@@ -566,11 +578,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
                 bool advance = true;
                 if (!second) {
                     col3 c = mkc(0, 0, 0);
-                    if (!occluded && !(kMax > l->cutoff_radius)) {
-                        float scale = attenuation(l, kMax * rcp_fast(l->attenuation_radius));
-                        scale = maxf_net(scale, 0);
-                        c = mkc(l->colour[0], l->colour[1], l->colour[2]) * mkc(scale, scale, scale);
-                    }
+                    if (!occluded) c = light_contribution<EXACT>(l, kMax);
                     if (!phong) sum = sum + c;
                     else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) { cdd = c * fabsf(dot(r.d, nrm)); second = true; advance = false; }
                 } else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {              // PhongMaterial.cs:42-56
@@ -583,14 +591,14 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
                 }
                 if (advance) { q++; li++; if (li == n_lights) li = 0; }
                 if (q == per_request) {                                         // ---- the request is complete: add its light to the path
-                    float S = (float)rd.light_samples, invS = rcp_fast(S);
-                    sum = sum * invS;
+                    const float S = (float)rd.light_samples;
+                    sum = over_samples<EXACT>(sum, S);
                     const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
                     const col3 W = mkc(e1.z, e1.w, e2.x);
                     const uint32_t dst = __float_as_uint(e2.z), id = __float_as_uint(e2.y);
                     col3 add;
                     if (!phong) add = W * sum;
-                    else { spec_sum = spec_sum * invS; add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
+                    else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
                     float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
                     float4 t = *tgt;
                     if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
@@ -613,7 +621,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
                 q = 0; li = 0; second = false; have = true;
             }
             if (have) {                                                         // ---- next ray of the request
-                ShadowRay sr = light_shadow_ray<C>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
+                ShadowRay sr = light_shadow_ray<C, EXACT>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
                 r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
                 rays++; flying = true; occluded = false;
                 for (uint32_t i = 0; i < sc.n_unbounded && !occluded; i++) {
@@ -626,7 +634,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
                         occluded = fast_object_solid<C>(sc, md.boundary_type, md.boundary_index, r, kMin, kMax);      // ConstantDensityMedium.cs:77
                     }
                 }
-                if (!occluded && sc.n_nodes) { invD = splat(1.0f) / r.d; cur = 0; sp = 0; }
+                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax); cur = 0; sp = 0; }
             }
         }
         next += (uint32_t)__popcll(__ballot(fetched));
@@ -635,7 +643,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
             continue;                                                           // (rays decided without the tree: account, draw again)
         }
         for (;;) {
-            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, r, invD, kMin, kMax, cur, pend, sp); }
+            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
             if (pend != TRAV_DONE) {
                 prims++;
                 if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) { occluded = true; cur = TRAV_DONE; pend = TRAV_DONE; }
@@ -650,6 +658,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, ShadowPersiste
     stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, nodes, prims);
 }
 
+#ifdef RT_KERNELS_COMMON
 // UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — passes of the batch are added in pass order.
 __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum, uint32_t n_passes) {
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < rd.n_pixels; pix += gridDim.x * BLOCK) {
@@ -665,6 +674,11 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum
     }
 }
 
+// n_devices > 1: another shard's colour sums into the combined buffer (rt_lib.hip: combine_shards)
+__global__ void __launch_bounds__(BLOCK) k_add(float* dst, const float* src, size_t n_values) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += (size_t)gridDim.x * BLOCK) dst[i] += src[i];
+}
+
 // RenderJob.cs:646-654 ; Colour.Clamp01 / Sqrt / (Rgb24), Colour.cs:197-234
 __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t sample_count, size_t n_values, uint8_t* out) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += (size_t)gridDim.x * BLOCK) {
@@ -676,7 +690,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t 
     }
 }
 
-// Parity hooks: one thread per caller-supplied ray.
+#endif
+
 // Parity hooks: one thread per caller-supplied ray, same device functions as the render kernels.
 template <class C, bool LDS>
 __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
@@ -685,7 +700,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_close
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         RngKey key = make_key(seed, (uint32_t)i, 0);
-        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        TravCount cnt = trav_count_zero();
         Closest c = closest_hit<C>(sc, tree, r, kMin, kMax, key, 0, cnt);
         rt_hit h = {};
         h.object = RT_NO_HIT; h.material = RT_NO_HIT;
@@ -707,7 +722,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(Sc
     const auto tree = make_tree<LDS, TB>(sc);
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
-        TravCount cnt; cnt.nodes = 0; cnt.prims = 0;
+        TravCount cnt = trav_count_zero();
         occluded[i] = any_hit<C>(sc, tree, r, kMin[i], kMax[i], cnt) ? 1 : 0;
     }
 }
@@ -736,6 +751,9 @@ struct KernelSet {
     // LdsTree forms (null when the variant has none)
     void (*closest_persistent)(SceneDev, RenderDev, uint32_t);     // heavy-tailed scenes (see k_closest_persistent)
     void (*shadow_persistent)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_exact)(SceneDev, RenderDev, uint32_t);           // light sampling in the reference's correctly rounded arithmetic (RT_RENDER_EXACT_LIGHT_SAMPLING)
+    void (*shadow_persistent_exact)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_lds_exact)(SceneDev, RenderDev, uint32_t);
     void (*closest_lds)(SceneDev, RenderDev, uint32_t);
     void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
@@ -743,9 +761,15 @@ struct KernelSet {
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
-                k_closest_persistent<C, false>, k_shadow_persistent<C, false>, nullptr, nullptr, nullptr, nullptr};
-    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+                k_closest_persistent<C, false>, k_shadow_persistent<C, false>, k_shadow<C, false, true>, k_shadow_persistent<C, false, true>, nullptr,
+                nullptr, nullptr, nullptr, nullptr};
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }
+
+
+// One translation unit per variant (rt_variant_*.hip) so that they compile in parallel; rt_lib.hip picks among them.
+extern const KernelSet ks_spheres, ks_mesh, ks_boxes, ks_all;
+extern void (*const k_shade_vis)(SceneDev, RenderDev, uint32_t);      // k_shade<CfgAll, true>: debug visualisations, any scene
 
 } // namespace rtd

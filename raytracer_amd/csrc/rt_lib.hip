@@ -8,12 +8,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_hip.h"
 #include "rt_bvh.h"
 namespace rtlbvh { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, std::string& err); }
+#define RT_KERNELS_COMMON
 #include "rt_kernels.h"
 
 using namespace rtd;
@@ -65,15 +68,18 @@ inline bool finite3(const float* a) { return std::isfinite(a[0]) && std::isfinit
 
 namespace {
 // most specific first; the last entry covers everything
-const KernelSet g_kernel_sets[] = {
-    make_kernel_set<CfgSpheres, true>("spheres"), make_kernel_set<CfgMesh, false>("mesh"), make_kernel_set<CfgBoxes, false>("boxes"), make_kernel_set<CfgAll, false>("generic"),
-};
+const KernelSet* const g_kernel_sets[] = {&ks_spheres, &ks_mesh, &ks_boxes, &ks_all};
 constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 } // namespace
 
+// every device buffer of a scene (X-macro: allocation, peer copy to a replica, pointer binding all walk the same list)
+#define RT_SCENE_BUFFERS(X) \
+    X(nodes) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
+    X(axis0) X(axis1) X(axis2) X(disks) X(boxes) X(capsules) X(cylinders) X(media_rec) X(materials) X(textures) X(lights)
+
 struct rt_scene {
     int device = 0;
-    const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
+    const KernelSet* ks = g_kernel_sets[N_KERNEL_SETS - 1];
     SceneDev dev{};
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
@@ -81,12 +87,38 @@ struct rt_scene {
     bool device_build = false;       // the tree was built by rt_lbvh.hip
     int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
-    DevBuf lds_image, list_nodes;
     uint32_t n_objects = 0, n_lights = 0;
     int n_cu = 256;
-    DevBuf nodes, obj_code, obj_material, unbounded, media, spheres, quads, triangles, inf_planes, axis[3], disks, boxes, capsules, cylinders,
-           media_rec, materials, textures, lights;
+    std::atomic<int> live_renders{0};            // rt_scene_destroy refuses while a render still uses the scene
+#define X(name) DevBuf name;
+    RT_SCENE_BUFFERS(X)
+#undef X
+    // staging of rt_trace_closest / rt_trace_any, kept between calls (grow-only up to TRACE_KEEP_BYTES)
+    DevBuf trace_in, trace_out, trace_k;
 };
+
+namespace {
+// SceneDev's pointers from the scene's own buffers (after upload, and after a replica's peer copies)
+void bind_scene_pointers(rt_scene* s) {
+    SceneDev& sd = s->dev;
+    sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>();
+    sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>();
+    sd.unbounded = s->unbounded.as<uint32_t>(); sd.media = s->media.as<uint32_t>();
+    sd.spheres = s->spheres.as<float4>(); sd.quads = s->quads.as<float4>(); sd.triangles = s->triangles.as<float4>(); sd.inf_planes = s->inf_planes.as<float4>();
+    sd.axis_planes[0] = s->axis0.as<float4>(); sd.axis_planes[1] = s->axis1.as<float4>(); sd.axis_planes[2] = s->axis2.as<float4>();
+    sd.disks = s->disks.as<float4>(); sd.boxes = s->boxes.as<float4>(); sd.capsules = s->capsules.as<float4>(); sd.cylinders = s->cylinders.as<float4>();
+    sd.media_rec = s->media_rec.as<rt_medium>(); sd.materials = s->materials.as<rt_material>(); sd.textures = s->textures.as<rt_texture>();
+    sd.lights = s->lights.as<rt_light>();
+}
+// more than 64 KB of dynamic LDS needs a per-function opt-in.  The attribute is per function and process-wide, so it is set to the
+// cap rt_scene_create admits (80 KB), never to one scene's need: a second scene cannot lower the first one's limit.
+constexpr size_t LDS_TREE_CAP = 80 * 1024;
+int allow_big_lds(const KernelSet* ks) {
+    const void* fns[5] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact};
+    for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
+    return RT_OK;
+}
+} // namespace
 
 // One batch in flight: its own path state, counters and stream.  Batches are independent until they add into the image
 // sums, so a few of them run concurrently: the deep bounces of one batch (few paths, latency-bound launches) overlap the
@@ -100,8 +132,10 @@ constexpr int MAX_SLOTS = 4;
 
 struct rt_render {
     rt_scene* scene = nullptr;
+    int device = 0;                  // the scene's device, cached: every entry point selects it
     rt_render_opts opts{};
     RenderDev rd{};                  // slot 0's view (shared fields)
+    bool exact_lights = false;       // RT_RENDER_EXACT_LIGHT_SAMPLING / RT_HIP_EXACT_LIGHTS=1
     uint32_t passes_per_batch = 1;
     size_t max_paths = 0;
     hipStream_t stream = nullptr; bool own_stream = false;     // the stream results are ordered on (slot 0's)
@@ -121,6 +155,11 @@ struct rt_render {
     std::vector<Stamp> stamps;              // recorded, not yet read
     std::vector<hipEvent_t> free_events;
     rt_kernel_profile prof{};
+    // n_devices > 1: this handle is a front for one single-device render per shard (shards[0] on the caller's scene, the others on
+    // replicas this handle owns); its own slots / streams stay empty.  `combined` and `gather` live on shards[0]'s device.
+    std::vector<rt_render*> shards;
+    std::vector<rt_scene*> replicas;
+    DevBuf combined, gather;
 };
 
 namespace {
@@ -191,8 +230,6 @@ static int check_prim(const rt_scene_desc* d, uint32_t type, uint32_t index, boo
     return RT_OK;
 }
 
-static inline size_t lds_tree_bytes_for(size_t image_bytes, uint32_t stack_depth, int block) { return image_bytes + (size_t)stack_depth * block * sizeof(unsigned short); }
-
 int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (!d || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
     *out = nullptr;
@@ -259,11 +296,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     for (uint32_t i = 0; i < d->n_lights; i++) { m_lights |= 1u << d->lights[i].type; if (d->lights[i].type == RT_LIGHT_DIFFUSE_SHAPED) m_prims |= 1u << d->lights[i].shape_type; }
     for (uint32_t i = 0; i < d->n_materials; i++) m_mats |= 1u << d->materials[i].type;
     for (uint32_t i = 0; i < d->n_textures; i++) m_texs |= 1u << d->textures[i].type;
-    const KernelSet* ks = &g_kernel_sets[N_KERNEL_SETS - 1];
+    const KernelSet* ks = g_kernel_sets[N_KERNEL_SETS - 1];
     const char* force = getenv("RT_HIP_VARIANT");
     if (!(force && !strcmp(force, "generic")))
         for (int i = 0; i < N_KERNEL_SETS; i++) {
-            const KernelSet& k = g_kernel_sets[i];
+            const KernelSet& k = *g_kernel_sets[i];
             if (!(m_prims & ~k.prims) && !(m_mats & ~k.mats) && !(m_texs & ~k.texs) && !(m_lights & ~k.lights)) { ks = &k; break; }
         }
 
@@ -361,11 +398,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                 memcpy(&ln[i], &h, sizeof(Node));
             }
             UP(list_nodes, ln);
-            s->dev.list = s->list_nodes.as<Node>(); s->dev.n_list_pairs = (uint32_t)ln.size();
+            s->dev.n_list_pairs = (uint32_t)ln.size();
         }
     }
     UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
-    UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis[0], axis[0]); UP(axis[1], axis[1]); UP(axis[2], axis[2]);
+    UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis0, axis[0]); UP(axis1, axis[1]); UP(axis2, axis[2]);
     UP(disks, disks); UP(boxes, bxs); UP(capsules, caps); UP(cylinders, cyls);
     std::vector<rt_medium> mrec(d->media, d->media + d->n_media);
     std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
@@ -374,16 +411,21 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     UP(media_rec, mrec); UP(materials, mats); UP(textures, texs); UP(lights, lts);
 #undef UP
     SceneDev& sd = s->dev;
-    sd.nodes = s->nodes.as<Node>(); sd.n_nodes = (uint32_t)n_nodes; sd.any_near_first = n_nodes >= 1024 ? 1u : 0u;
-    sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>(); sd.n_objects = d->n_objects;
-    sd.unbounded = s->unbounded.as<uint32_t>(); sd.n_unbounded = (uint32_t)unbounded.size();
-    sd.media = s->media.as<uint32_t>(); sd.n_media = (uint32_t)media.size();
-    sd.spheres = s->spheres.as<float4>(); sd.quads = s->quads.as<float4>(); sd.triangles = s->triangles.as<float4>(); sd.inf_planes = s->inf_planes.as<float4>();
-    for (int a = 0; a < 3; a++) sd.axis_planes[a] = s->axis[a].as<float4>();
-    sd.disks = s->disks.as<float4>(); sd.boxes = s->boxes.as<float4>(); sd.capsules = s->capsules.as<float4>(); sd.cylinders = s->cylinders.as<float4>();
-    sd.media_rec = s->media_rec.as<rt_medium>(); sd.materials = s->materials.as<rt_material>(); sd.textures = s->textures.as<rt_texture>();
-    sd.lights = s->lights.as<rt_light>(); sd.n_lights = d->n_lights;
+    bind_scene_pointers(s.get());
+    sd.n_nodes = (uint32_t)n_nodes; sd.any_near_first = n_nodes >= 1024 ? 1u : 0u;
+    sd.n_objects = d->n_objects; sd.n_unbounded = (uint32_t)unbounded.size(); sd.n_media = (uint32_t)media.size(); sd.n_lights = d->n_lights;
     sd.camera = d->camera; sd.skybox = d->skybox;
+    {   // any_pad (rt_device.h): a sphere around every bounded object and the largest object's half-diagonal, in double on the host
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, max_half = 0.0;
+        for (const rtbvh::Box& b : boxes) {
+            double dd = 0.0;
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)b.mn[a]); hi[a] = std::max(hi[a], (double)b.mx[a]); const double e = 0.5 * ((double)b.mx[a] - b.mn[a]); dd += e * e; }
+            max_half = std::max(max_half, std::sqrt(dd));
+        }
+        double r2 = 0.0;
+        for (int a = 0; a < 3; a++) { const double c = boxes.empty() ? 0.0 : 0.5 * (lo[a] + hi[a]), e = boxes.empty() ? 0.0 : 0.5 * (hi[a] - lo[a]); sd.bounds_centre[a] = (float)c; r2 += e * e; }
+        sd.bounds_radius = (float)(std::sqrt(r2) * 1.0001 + 1e-6); sd.max_object_radius = (float)(max_half * 1.0001);
+    }
     s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2); s->bvh_depth = bvh.max_depth;
     if ((size_t)s->stack_depth * BLOCK * sizeof(int) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "BVH depth %u needs more LDS than one workgroup may use", bvh.max_depth);
     s->n_objects = d->n_objects; s->n_lights = d->n_lights;
@@ -392,23 +434,28 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         bool all_spheres = ks->closest_lds != nullptr && !nodes.empty();
         for (uint32_t obj : box_obj) all_spheres = all_spheres && d->objects[obj].type == RT_HIT_SPHERE;
         const size_t nn = nodes.size(), no = d->n_objects;
-        const size_t image_bytes = (3 * nn + (nn + 1) / 2 + no) * 16;
+        const size_t image_bytes = nn * LDS_NODE_BYTES + no * 16;
         const size_t need = image_bytes + (size_t)s->stack_depth * LDS_BLOCK_CLOSEST * sizeof(unsigned short);
         const char* no_lds = getenv("RT_HIP_NO_LDS_TREE");
-        if (all_spheres && !s->dev.n_list_pairs && nn < 32768 && no < 32768 && need <= 80 * 1024 && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+        if (all_spheres && !s->dev.n_list_pairs && nn < 32768 && no < 32768 && need <= LDS_TREE_CAP && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+            // node record (rt_device.h LdsTree): per axis (min A, min B, max A, max B, min A, min B), then (child A, child B)
+            static_assert(LDS_NODE_BYTES == 80 && LDS_NODE_BYTES % 16 == 0, "LDS node layout");
             std::vector<float4> img(image_bytes / 16, make_float4(0, 0, 0, 0));
-            for (size_t i = 0; i < nn; i++) { img[i] = nodes[i].q0; img[nn + i] = nodes[i].q1; img[2 * nn + i] = nodes[i].q2; }
-            int2* chp = (int2*)(img.data() + 3 * nn);
-            for (size_t i = 0; i < nn; i++) chp[i] = make_int2(nodes[i].q3.x, nodes[i].q3.y);
-            float4* sp = img.data() + 3 * nn + (nn + 1) / 2;
+            for (size_t i = 0; i < nn; i++) {
+                const rtbvh::HostNode& h = bvh.nodes[i];              // q = min.x(A,B) min.y(A,B) min.z(A,B) max.x(A,B) max.y(A,B) max.z(A,B)
+                float* rec = (float*)img.data() + i * (LDS_NODE_BYTES / 4);
+                for (int a = 0; a < 3; a++) {
+                    float* ax = rec + 6 * a;
+                    ax[0] = h.q[2 * a]; ax[1] = h.q[2 * a + 1]; ax[2] = h.q[6 + 2 * a]; ax[3] = h.q[6 + 2 * a + 1]; ax[4] = ax[0]; ax[5] = ax[1];
+                }
+                memcpy(rec + 18, &h.childA, 4); memcpy(rec + 19, &h.childB, 4);
+            }
+            float4* sp = img.data() + nn * (LDS_NODE_BYTES / 16);
             for (size_t i = 0; i < no; i++) if (d->objects[i].type == RT_HIT_SPHERE) sp[i] = spheres[d->objects[i].index];
             if ((rc = upload(s->lds_image, img))) return rc;
             sd.lds_image = s->lds_image.as<uint4>(); sd.lds_image_bytes = (uint32_t)image_bytes;
             s->use_lds = true;
-            // more than 64 KB of dynamic LDS needs the per-function opt-in
-            const void* fns[4] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds};
-            for (int i = 0; i < 4; i++)
-                HIP_TRY(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tree_bytes_for(image_bytes, s->stack_depth, i < 2 ? LDS_BLOCK_CLOSEST : LDS_BLOCK_SHADOW)));
+            if ((rc = allow_big_lds(ks))) return rc;
         }
     }
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 1014 Msamples/s with
@@ -431,8 +478,33 @@ int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
 
 int rt_scene_destroy(rt_scene* s) {
     if (!s) return RT_OK;
+    // every rt_render_* call reads its scene: destroying the scene first would leave the renders with dangling device pointers
+    if (s->live_renders.load() > 0) return fail(RT_ERR_INVALID_ARG, "rt_scene_destroy: %d render(s) still use this scene; destroy them first", s->live_renders.load());
     DeviceGuard guard(s->device);
     delete s;
+    return RT_OK;
+}
+
+// A copy of `src` on `device` for rt_render_create's n_devices > 1: every table and the BVH travel by peer copy (xGMI), nothing is
+// rebuilt — the replica's tree is the source's bit for bit, so every shard traces the same arithmetic.
+static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
+    *out = nullptr;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
+    auto s = std::make_unique<rt_scene>();
+    s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
+    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->persistent = src->persistent;
+    s->n_objects = src->n_objects; s->n_lights = src->n_lights;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#define X(name) if (src->name.bytes) { HIP_TRY(s->name.alloc(src->name.bytes)); HIP_TRY(hipMemcpyPeer(s->name.p, device, src->name.p, src->device, src->name.bytes)); }
+    RT_SCENE_BUFFERS(X)
+#undef X
+    HIP_TRY(hipDeviceSynchronize());
+    bind_scene_pointers(s.get());
+    if (s->use_lds) if (int rc = allow_big_lds(s->ks)) return rc;
+    *out = s.release();
     return RT_OK;
 }
 
@@ -456,19 +528,33 @@ static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) {
 // -------------------------------------------------------------------------------------------------
 // Parity hooks
 // -------------------------------------------------------------------------------------------------
+// Staging for the two hooks lives in the scene and is reused by later calls (the hooks are the public TryFindClosestHit /
+// AnyIntersectionFast replacements, RenderJob.cs:575-617: a caller that asks often must not pay two hipMallocs per call).  A request
+// beyond TRACE_KEEP_BYTES still works; its buffers are released again afterwards.
+constexpr size_t TRACE_KEEP_BYTES = 256u << 20;
+static int trace_staging(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return RT_OK;
+    HIP_TRY(b.alloc(bytes));
+    return RT_OK;
+}
+static void trace_release_large(rt_scene* s) {
+    for (DevBuf* b : {&s->trace_in, &s->trace_out, &s->trace_k}) if (b->bytes > TRACE_KEEP_BYTES) (void)b->alloc(0);
+}
+
 int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits) {
     if (!s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_trace_closest: null argument");
     if (!n) return RT_OK;
     if (n > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest: at most 2^31 rays per call");
     DeviceGuard guard(s->device);
-    DevBuf dr, dh;
-    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dh.alloc(n * sizeof(rt_hit)));
-    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
-    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), n, k_min, k_max, seed, dh.as<rt_hit>());
+    if (int rc = trace_staging(s->trace_in, n * sizeof(rt_ray))) return rc;
+    if (int rc = trace_staging(s->trace_out, n * sizeof(rt_hit))) return rc;
+    rt_ray* dr = s->trace_in.as<rt_ray>(); rt_hit* dh = s->trace_out.as<rt_hit>();
+    HIP_TRY(hipMemcpy(dr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, dr, n, k_min, k_max, seed, dh);
+    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, n, k_min, k_max, seed, dh);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hits, dh, n * sizeof(rt_hit), hipMemcpyDeviceToHost));           // (null stream: ordered after the kernel, blocks until the copy is done)
+    trace_release_large(s);
     return RT_OK;
 }
 
@@ -477,16 +563,18 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     if (!n) return RT_OK;
     if (n > (1ull << 31)) return fail(RT_ERR_TOO_LARGE, "rt_trace_any: at most 2^31 rays per call");
     DeviceGuard guard(s->device);
-    DevBuf dr, d0, d1, dout;
-    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(d0.alloc(n * sizeof(float))); HIP_TRY(d1.alloc(n * sizeof(float))); HIP_TRY(dout.alloc(n));
-    HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d0.p, k_min, n * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d1.p, k_max, n * sizeof(float), hipMemcpyHostToDevice));
-    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
-    else hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr.as<rt_ray>(), d0.as<float>(), d1.as<float>(), n, dout.as<uint8_t>());
+    if (int rc = trace_staging(s->trace_in, n * sizeof(rt_ray))) return rc;
+    if (int rc = trace_staging(s->trace_k, 2 * n * sizeof(float))) return rc;
+    if (int rc = trace_staging(s->trace_out, n)) return rc;
+    rt_ray* dr = s->trace_in.as<rt_ray>(); float* d0 = s->trace_k.as<float>(); float* d1 = d0 + n; uint8_t* dout = s->trace_out.as<uint8_t>();
+    HIP_TRY(hipMemcpy(dr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d0, k_min, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d1, k_max, n * sizeof(float), hipMemcpyHostToDevice));
+    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), 0, s->dev, dr, d0, d1, n, dout);
+    else hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(occluded, dout.p, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(occluded, dout, n, hipMemcpyDeviceToHost));
+    trace_release_large(s);
     return RT_OK;
 }
 
@@ -495,6 +583,10 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
 // -------------------------------------------------------------------------------------------------
 // everything a render handle owns (also the clean-up of a half-built one: rt_render_create fails through it)
 static void release_render(rt_render* r) {
+    for (rt_render* sh : r->shards) if (sh) { DeviceGuard g(sh->device); release_render(sh); }
+    r->shards.clear();
+    for (rt_scene* sc : r->replicas) if (sc) { DeviceGuard g(sc->device); delete sc; }
+    r->replicas.clear();
     for (int si = 0; si < MAX_SLOTS; si++) if (r->slots[si].stream) (void)hipStreamSynchronize(r->slots[si].stream);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     collect_stamps(r);
@@ -505,13 +597,12 @@ static void release_render(rt_render* r) {
     }
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->scene) r->scene->live_renders.fetch_sub(1);
     delete r;
 }
 struct RenderDeleter { void operator()(rt_render* r) const { release_render(r); } };
 
-int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
-    if (!s || !o || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_create: null argument");
-    *out = nullptr;
+static int check_render_opts(const rt_render_opts* o) {
     if (o->struct_size != sizeof(rt_render_opts)) return fail(RT_ERR_INVALID_ARG, "rt_render_opts size mismatch (got %u, want %zu)", o->struct_size, sizeof(rt_render_opts));
     if (o->width < 1 || o->height < 1) return fail(RT_ERR_INVALID_ARG, "Image cannot have a width/height of less than 1 pixel");          // RenderOptions.cs:52,63
     if (o->k_min < 0 || std::isnan(o->k_min)) return fail(RT_ERR_INVALID_ARG, "KMin cannot have a value of less than 0");                   // :74
@@ -520,32 +611,53 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->debug_visualisation > RT_VIS_BOUNCE_DEPTH || o->debug_visualisation == RT_VIS_UNDEFINED_TEST)
         return fail(RT_ERR_INVALID_ARG, "Wrong enum value for debug visualisation (%u)", o->debug_visualisation);                           // RenderJob.cs:307-308
     if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
+    if ((uint64_t)o->width * o->height > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
+    if (o->flags & ~RT_RENDER_EXACT_LIGHT_SAMPLING) return fail(RT_ERR_INVALID_ARG, "unknown bits in rt_render_opts.flags (0x%x)", o->flags);
+    if (o->n_devices > RT_MAX_DEVICES) return fail(RT_ERR_TOO_LARGE, "n_devices %u above RT_MAX_DEVICES (%d)", o->n_devices, RT_MAX_DEVICES);
+    return RT_OK;
+}
+
+// one GPU: the scene's
+static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     if (o->device >= 0 && o->device != s->device) return fail(RT_ERR_INVALID_ARG, "render device %d differs from the scene's device %d", o->device, s->device);
     const uint64_t n_pixels = (uint64_t)o->width * o->height;
-    if (n_pixels > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
 
     DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", s->device);
     std::unique_ptr<rt_render, RenderDeleter> r(new rt_render());
-    r->scene = s; r->opts = *o;
+    r->scene = s; r->device = s->device; r->opts = *o;
+    s->live_renders.fetch_add(1);
+    { const char* e = getenv("RT_HIP_EXACT_LIGHTS"); r->exact_lights = (o->flags & RT_RENDER_EXACT_LIGHT_SAMPLING) || (e && e[0] == '1'); }
     // paths per batch: the alive paths fall to ~1 % by bounce 10, and a launch needs >> 0.5 M rays to fill 256 CUs, so batches are
-    // big (128 M paths = 26 GB of state per slot): sized for 288 GB of HBM, not for a cache
+    // big (128 M paths = 26 GB of state per slot): sized for 288 GB of HBM, not for a cache — but never for more passes than the
+    // caller will ask for in one call (max_passes_per_call), and never for more than the device has free right now.
     const uint64_t target_paths = 128ull << 20;
-    uint32_t ppb = o->passes_per_batch ? o->passes_per_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
+    uint32_t ppb = o->passes_per_batch;
+    if (!ppb) {
+        ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
+        if (o->max_passes_per_call) ppb = std::min(ppb, o->max_passes_per_call);
+    }
     if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
     // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob)
     int n_slots = 2;
     if (const char* e = getenv("RT_HIP_SLOTS")) n_slots = std::max(1, std::min(MAX_SLOTS, atoi(e)));
-    // path state: float4 arrays (2 x 4 state, 1 out, 3 (+1) shadow), then hit (float2) and hit_aux (float).  passes_per_batch is an
-    // upper bound: when the device cannot hold it (another job, a smaller card) the batch is halved until it fits.
+    // path state: float4 arrays (2 x 3 state, 1 out, 3 (+1) shadow), then ids (2 x uint2), hit (float2) and hit_aux (float).
+    // passes_per_batch is an upper bound: when the device cannot hold it (another job, a smaller card) the batch is halved until it fits.
     const bool has_phong = (s->ks->mats >> RT_MAT_PHONG) & 1u, has_medium = (s->ks->prims >> RT_HIT_MEDIUM) & 1u;
     const size_t n_f4 = 6 + 1 + 3 + (has_phong ? 1 : 0);
     const size_t bytes_per_path = n_f4 * sizeof(float4) + 2 * sizeof(uint2) + sizeof(float2) + (has_medium ? sizeof(float) : 0);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b)
+            while (ppb > 1 && (double)n_pixels * ppb * bytes_per_path * n_slots > 0.92 * (double)free_b) ppb = std::max<uint32_t>(1, ppb / 2);
+    }
     for (;;) {
-        bool ok = true;
-        for (int si = 0; si < n_slots && ok; si++) ok = r->slots[si].f32_pool.alloc((size_t)(n_pixels * ppb) * bytes_per_path) == hipSuccess;
-        if (ok) break;
+        hipError_t e = hipSuccess;
+        for (int si = 0; si < n_slots && e == hipSuccess; si++) e = r->slots[si].f32_pool.alloc((size_t)(n_pixels * ppb) * bytes_per_path);
+        if (e == hipSuccess) break;
         (void)hipGetLastError();
         for (int si = 0; si < n_slots; si++) (void)r->slots[si].f32_pool.alloc(0);
+        if (e != hipErrorOutOfMemory) return fail(RT_ERR_HIP, "hipMalloc of the path state failed: %s", hipGetErrorString(e));     // only a shortage of memory is a reason to shrink
         if (ppb == 1) return fail(RT_ERR_OUT_OF_MEMORY, "not enough device memory for the path state of one pass (%zu bytes per slot)", (size_t)n_pixels * bytes_per_path);
         ppb = std::max<uint32_t>(1, ppb / 2);
     }
@@ -599,9 +711,49 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
     return RT_OK;
 }
 
+int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
+    if (!s || !o || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_create: null argument");
+    *out = nullptr;
+    if (int rc = check_render_opts(o)) return rc;
+    if (o->n_devices <= 1) {
+        if (o->n_devices == 1 && o->device_ids[0] != s->device) return fail(RT_ERR_INVALID_ARG, "device_ids[0] = %d differs from the scene's device %d", o->device_ids[0], s->device);
+        return create_single(s, o, out);
+    }
+    // ---- several GPUs behind one handle: shard 0 on the caller's scene, shard g on a peer copy of it on device_ids[g]
+    if (o->stream || o->accum_device) return fail(RT_ERR_INVALID_ARG, "stream / accum_device belong to one device: they must be NULL when n_devices > 1");
+    if (o->device_ids[0] != s->device) return fail(RT_ERR_INVALID_ARG, "device_ids[0] = %d must be the scene's device %d (the shards are combined there)", o->device_ids[0], s->device);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
+    for (uint32_t g = 0; g < o->n_devices; g++)
+        if (o->device_ids[g] < 0 || o->device_ids[g] >= ndev) return fail(RT_ERR_INVALID_ARG, "device_ids[%u] = %d out of range (%d visible)", g, o->device_ids[g], ndev);
+    std::unique_ptr<rt_render, RenderDeleter> r(new rt_render());
+    r->scene = s; r->device = s->device; r->opts = *o;
+    s->live_renders.fetch_add(1);
+    rt_render_opts so = *o;
+    so.n_devices = 0; so.device = -1;
+    // a call's passes are split G ways, so a shard never sees more than ceil(max / G) of them
+    if (so.max_passes_per_call) so.max_passes_per_call = (so.max_passes_per_call + o->n_devices - 1) / o->n_devices;
+    for (uint32_t g = 0; g < o->n_devices; g++) {
+        rt_scene* sc = s;
+        if (g > 0) {
+            if (int rc = clone_scene(s, o->device_ids[g], &sc)) return rc;
+            r->replicas.push_back(sc);
+        }
+        rt_render* sh = nullptr;
+        if (int rc = create_single(sc, &so, &sh)) return rc;
+        r->shards.push_back(sh);
+    }
+    DeviceGuard guard(s->device);
+    const size_t bytes = (size_t)o->width * o->height * 3 * sizeof(float);
+    HIP_TRY(r->combined.alloc(bytes)); HIP_TRY(r->gather.alloc(bytes));
+    r->rd = r->shards[0]->rd;
+    *out = r.release();
+    return RT_OK;
+}
+
 int rt_render_destroy(rt_render* r) {
     if (!r) return RT_OK;
-    DeviceGuard guard(r->scene->device);
+    DeviceGuard guard(r->device);
     release_render(r);
     return RT_OK;
 }
@@ -620,7 +772,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     const bool first_hit_only = vis != RT_VIS_NONE && vis != RT_VIS_BOUNCE_DEPTH;
     const uint32_t max_depth = first_hit_only ? 0u : r->opts.max_bounce_depth;
     if (first_hit_only) rd.max_depth = 0;
-    auto shade_kernel = vis != RT_VIS_NONE ? k_shade<CfgAll, true> : ks->shade;
+    auto shade_kernel = vis != RT_VIS_NONE ? k_shade_vis : ks->shade;
     const bool trace_shadows = s->n_lights && (vis == RT_VIS_NONE || vis == RT_VIS_ESTIMATED_LIGHT);
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
@@ -628,6 +780,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     // A request with many rays (64 lights: 64 traversals, each ending at its own time) is where a lane should not wait for its
     // wave: 100 k spheres + 64 lights 766 -> 728 ms per batch; with 2-4 rays per request the refill rounds cost more than they save.
     const bool shadow_persistent = s->persistent_shadow >= 0 ? s->persistent_shadow != 0 : (uint64_t)rd.light_samples * s->n_lights >= 32;
+    const bool ex = r->exact_lights;
     { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
@@ -635,8 +788,8 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (s->use_lds) hipLaunchKernelGGL(ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
-          else hipLaunchKernelGGL(shadow_persistent ? ks->shadow_persistent : ks->shadow, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on
     if (r->batches_enqueued > 0 && r->n_slots > 1) HIP_TRY(hipStreamWaitEvent(st, r->ev_acc[(si + r->n_slots - 1) % r->n_slots], 0));
@@ -647,10 +800,9 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     return RT_OK;
 }
 
-int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride) {
-    if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_passes: null handle");
-    if (pass_stride < 1) pass_stride = 1;
-    DeviceGuard guard(r->scene->device);
+static int render_passes_single(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride) {
+    DeviceGuard guard(r->device);
+    if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", r->device);
     // per-kernel event timing wants kernels that do not overlap: one slot while profiling
     const int n_slots = r->profiling ? 1 : r->n_slots;
     // the other slots start after whatever the caller already queued on the main stream
@@ -679,10 +831,49 @@ int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint3
     return RT_OK;
 }
 
+int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride) {
+    if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_passes: null handle");
+    if (pass_stride < 1) pass_stride = 1;
+    if (r->shards.empty()) return render_passes_single(r, first_pass, n_passes, pass_stride);
+    // Pass i of this call (global pass first + i * stride) goes to shard i mod G: shard g renders first + g * stride, then every
+    // G-th from there.  One host thread per device drives its shard's streams; the call returns when every shard has finished.
+    const uint32_t G = (uint32_t)r->shards.size();
+    std::vector<int> rcs(G, RT_OK); std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t n_g = n_passes > g ? (n_passes - g + G - 1) / G : 0;
+        if (!n_g) continue;
+        th.emplace_back([=, &rcs, &errs] {
+            rcs[g] = render_passes_single(r->shards[g], first_pass + (uint64_t)g * pass_stride, n_g, pass_stride * G);
+            if (rcs[g]) errs[g] = g_err;                                   // (g_err is per thread)
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t g = 0; g < G; g++) if (rcs[g]) return fail(rcs[g], "device %d: %s", r->shards[g]->device, errs[g].c_str());
+    r->sample_count += n_passes; r->passes_rendered += n_passes;
+    return RT_OK;
+}
+
+// n_devices > 1: the shards' colour sums, added in shard order on shards[0]'s device -> r->combined.  Peer copies (xGMI) of
+// width*height*3 floats per shard (24.9 MB at 1080p, 99.5 MB at 4K), one add kernel each: the one exchange step of the path.
+static int combine_shards(rt_render* r) {
+    rt_render* r0 = r->shards[0];
+    const size_t nv = (size_t)r->rd.n_pixels * 3, bytes = nv * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(r->combined.p, r0->accum, bytes, hipMemcpyDeviceToDevice, r0->stream));
+    for (size_t g = 1; g < r->shards.size(); g++) {
+        rt_render* sh = r->shards[g];
+        HIP_TRY(hipMemcpyPeerAsync(r->gather.p, r0->device, sh->accum, sh->device, bytes, r0->stream));
+        hipLaunchKernelGGL(k_add, dim3(grid_for(r0->scene, nv, 8)), dim3(BLOCK), 0, r0->stream, r->combined.as<float>(), r->gather.as<float>(), nv);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
 int rt_render_resolve_device(rt_render* r, const float* accum_device, uint32_t sample_count, uint8_t* dst_host) {
     if (!r || !accum_device || !dst_host) return fail(RT_ERR_INVALID_ARG, "rt_render_resolve_device: null argument");
     if (sample_count < 1) return fail(RT_ERR_INVALID_ARG, "rt_render_resolve_device: no samples to resolve");
-    DeviceGuard guard(r->scene->device);
+    if (!r->shards.empty()) r = r->shards[0];
+    DeviceGuard guard(r->device);
     const size_t nv = (size_t)r->rd.n_pixels * 3;
     { Timed t(r, RT_K_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(grid_for(r->scene, nv, 8)), dim3(BLOCK), 0, r->stream, accum_device, sample_count, nv, r->rgb.as<uint8_t>()); }
     HIP_TRY(hipGetLastError());
@@ -696,36 +887,55 @@ int rt_render_read_rgb24(rt_render* r, uint8_t* dst) {
     if (!r || !dst) return fail(RT_ERR_INVALID_ARG, "rt_render_read_rgb24: null argument");
     // before the first pass the reference's Image<Rgb24> is what its constructor left: black (UpdateBuffers has not run, RenderJob.cs:40-47)
     if (r->sample_count == 0) { memset(dst, 0, (size_t)r->rd.n_pixels * 3); return RT_OK; }
-    return rt_render_resolve_device(r, r->accum, r->sample_count, dst);
+    if (r->shards.empty()) return rt_render_resolve_device(r, r->accum, r->sample_count, dst);
+    DeviceGuard guard(r->device);
+    if (int rc = combine_shards(r)) return rc;
+    return rt_render_resolve_device(r, r->combined.as<float>(), r->sample_count, dst);      // (same stream as the adds)
 }
 
 int rt_render_read_accum(rt_render* r, float* rgb_sum, uint32_t* sample_count) {
     if (!r || !rgb_sum) return fail(RT_ERR_INVALID_ARG, "rt_render_read_accum: null argument");
-    DeviceGuard guard(r->scene->device);
-    HIP_TRY(hipMemcpyAsync(rgb_sum, r->accum, (size_t)r->rd.n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    DeviceGuard guard(r->device);
+    const float* src = r->accum; hipStream_t st = r->stream;
+    if (!r->shards.empty()) { if (int rc = combine_shards(r)) return rc; src = r->combined.as<float>(); st = r->shards[0]->stream; }
+    HIP_TRY(hipMemcpyAsync(rgb_sum, src, (size_t)r->rd.n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (sample_count) *sample_count = r->sample_count;
     return RT_OK;
 }
 
-int rt_render_stats(rt_render* r, rt_stats* out) {
-    if (!r || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_stats: null argument");
-    DeviceGuard guard(r->scene->device);
+static int stats_single(rt_render* r, rt_stats* out) {
+    DeviceGuard guard(r->device);
     HIP_TRY(hipMemcpyAsync(r->stats_host.data(), r->stats.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     const auto& h = r->stats_host;
     memset(out, 0, sizeof(*out));
     out->pixels_rendered = h[ST_SAMPLES]; out->passes_rendered = r->passes_rendered;
     out->material_scatter_count = h[ST_SCATTER]; out->material_absorbed_count = h[ST_ABSORBED];
+    out->aabb_misses = h[ST_BOX_MISS]; out->hittable_intersections = h[ST_PRIM_HIT]; out->hittable_misses = h[ST_PRIMS] - h[ST_PRIM_HIT];
     out->sky_rays = h[ST_SKY]; out->bounce_limit_exceeded = h[ST_LIMIT]; out->ray_count = h[ST_RAYS]; out->shadow_rays = h[ST_SHADOW_RAYS];
     out->node_visits = h[ST_NODES]; out->prim_tests = h[ST_PRIMS]; out->shadow_node_visits = h[ST_SH_NODES]; out->shadow_prim_tests = h[ST_SH_PRIMS];
     for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) out->ray_depth_counts[i] = h[ST_DEPTH0 + i];
     return RT_OK;
 }
 
+int rt_render_stats(rt_render* r, rt_stats* out) {
+    if (!r || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_stats: null argument");
+    if (r->shards.empty()) return stats_single(r, out);
+    memset(out, 0, sizeof(*out));
+    static_assert(sizeof(rt_stats) % sizeof(uint64_t) == 0, "rt_stats is an array of 64-bit counters");
+    for (rt_render* sh : r->shards) {                      // every field is a count: the job's statistics are the shards' sums
+        rt_stats one;
+        if (int rc = stats_single(sh, &one)) return rc;
+        for (size_t i = 0; i < sizeof(rt_stats) / sizeof(uint64_t); i++) ((uint64_t*)out)[i] += ((const uint64_t*)&one)[i];
+    }
+    return RT_OK;
+}
+
 int rt_render_set_profiling(rt_render* r, int enable) {
     if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_set_profiling: null handle");
-    DeviceGuard guard(r->scene->device);
+    if (!r->shards.empty()) { for (rt_render* sh : r->shards) if (int rc = rt_render_set_profiling(sh, enable)) return rc; return RT_OK; }
+    DeviceGuard guard(r->device);
     HIP_TRY(hipStreamSynchronize(r->stream));
     collect_stamps(r);
     r->profiling = enable != 0;
@@ -735,7 +945,16 @@ int rt_render_set_profiling(rt_render* r, int enable) {
 
 int rt_render_kernel_profile(rt_render* r, rt_kernel_profile* out) {
     if (!r || !out) return fail(RT_ERR_INVALID_ARG, "rt_render_kernel_profile: null argument");
-    DeviceGuard guard(r->scene->device);
+    if (!r->shards.empty()) {                              // launches and milliseconds summed over the shards (they run side by side)
+        memset(out, 0, sizeof(*out));
+        for (rt_render* sh : r->shards) {
+            rt_kernel_profile one;
+            if (int rc = rt_render_kernel_profile(sh, &one)) return rc;
+            for (int k = 0; k < RT_K_COUNT; k++) { out->launches[k] += one.launches[k]; out->total_ms[k] += one.total_ms[k]; }
+        }
+        return RT_OK;
+    }
+    DeviceGuard guard(r->device);
     HIP_TRY(hipStreamSynchronize(r->stream));
     collect_stamps(r);
     *out = r->prof;

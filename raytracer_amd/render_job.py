@@ -48,6 +48,19 @@ class DeviceScene:
         self._lib = capi.load()
         self.handle = C.c_void_p()
         capi.check(self._lib.rt_scene_create(C.byref(self.flat.desc), device, C.byref(self.handle)))
+        if device < 0:
+            n = C.c_int(0)
+            device = 0
+            try:
+                import torch
+                device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            except Exception:
+                pass
+        self._device = device
+
+    def DeviceOrdinal(self) -> int:
+        """The HIP device the scene lives on (-1 at construction = HIP's current device at that time)."""
+        return self._device
 
     def Info(self) -> dict:
         """Shape of the device BVH and the kernel variant chosen (rt_scene_get_info)."""
@@ -75,9 +88,10 @@ class DeviceScene:
         return out.astype(bool)
 
     def Dispose(self):
+        """rt_scene_destroy refuses while a render still uses the scene (destroy the RenderJobs first); the handle is kept then."""
         if self.handle:
-            self._lib.rt_scene_destroy(self.handle)
-            self.handle = C.c_void_p()
+            if self._lib.rt_scene_destroy(self.handle) == 0:
+                self.handle = C.c_void_p()
 
     def __del__(self):
         try:
@@ -99,7 +113,7 @@ def _pack_rays(origins, directions) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate([o, d], axis=1))
 
 
-def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0) -> capi.RenderOpts:
+def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0, devices=None, max_passes_per_call=0) -> capi.RenderOpts:
     ro = capi.RenderOpts()
     ro.struct_size = C.sizeof(capi.RenderOpts)
     ro.width, ro.height = o.RenderWidth, o.RenderHeight
@@ -107,37 +121,51 @@ def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0) -> capi.Ren
     ro.max_bounce_depth, ro.light_sample_count_hint = o.MaxBounceDepth, o.LightSampleCountHint
     ro.debug_visualisation = o.DebugVisualisation
     ro.seed = o.Seed
-    # 0 = library default (up to 64 passes / 128 M paths per batch); never allocate state for more passes than the job renders
-    ro.passes_per_batch = o.PassesPerBatch or min(64, max(1, (128 << 20) // max(1, o.RenderWidth * o.RenderHeight)), max(1, o.Passes))
+    ro.passes_per_batch = o.PassesPerBatch                # 0 = the library's choice: min(64, 128 M paths / pixels, max_passes_per_call)
+    ro.max_passes_per_call = max_passes_per_call or max(1, o.Passes)      # never path state for more passes than the job renders
     ro.device = device
     ro.stream = stream or None
     ro.accum_device = accum_device or None
+    ro.flags = capi.RENDER_EXACT_LIGHT_SAMPLING if getattr(o, "ExactLightSampling", False) else 0
+    if devices:
+        if len(devices) > capi.RT_MAX_DEVICES:
+            raise ValueError(f"at most {capi.RT_MAX_DEVICES} devices")
+        ro.n_devices = len(devices)
+        for i, d in enumerate(devices):
+            ro.device_ids[i] = int(d)
     return ro
 
 
 class RenderJob:
     def __init__(self, scene: Scene, renderOptions: RenderOptions, device: int = -1, rank: int = 0, world_size: int = 1,
-                 process_group=None, device_scene: Optional[DeviceScene] = None):
+                 process_group=None, device_scene: Optional[DeviceScene] = None, devices=None):
+        """devices=[d0, d1, ...]: ONE process, several GPUs — the library shards every call's passes over them and combines the sums
+        on d0 (rt_render_opts.n_devices).  rank / world_size: one process per GPU, combined by ReduceToRoot (RCCL)."""
         self.Scene, self.RenderOptions = scene, renderOptions
         self.rank, self.world_size, self.process_group = rank, world_size, process_group
         self._lib = capi.load()
+        if devices and device_scene is None:
+            device = devices[0]
         self.device_scene = device_scene or DeviceScene(scene, device)
         W, H = renderOptions.RenderWidth, renderOptions.RenderHeight
         self.ImageBuffer = np.zeros((H, W, 3), dtype=np.uint8)
         self._accum_tensor = None
         accum_ptr = 0
         if world_size > 1:
-            # the sums live in a torch tensor so torch.distributed (RCCL) can reduce them in place
+            if devices:
+                raise ValueError("devices= (one process, several GPUs) and world_size > 1 (one process per GPU) exclude each other")
+            # the sums live in a torch tensor so torch.distributed (RCCL) can reduce them in place — on the SCENE's device
             import torch
-            self._accum_tensor = torch.zeros(H * W * 3, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-            torch.cuda.synchronize()
+            self._accum_tensor = torch.zeros(H * W * 3, dtype=torch.float32, device=torch.device("cuda", self.device_scene.DeviceOrdinal()))
+            torch.cuda.synchronize(self._accum_tensor.device)
             accum_ptr = self._accum_tensor.data_ptr()
-        self._opts = make_opts(renderOptions, device=-1, accum_device=accum_ptr)
+        self._opts = make_opts(renderOptions, device=-1, accum_device=accum_ptr, devices=devices)
         self.handle = C.c_void_p()
         capi.check(self._lib.rt_render_create(self.device_scene.handle, C.byref(self._opts), C.byref(self.handle)))
         self.RenderStats = RenderStats(TotalTruePixels=W * H, TotalPasses=renderOptions.Passes)
         self.RenderTask: Optional[Future] = None
         self.RenderCompleted = False
+        self.Cancelled = False
         self._started = threading.Lock()
         self._cancel = threading.Event()
         self._passes_done = 0            # this rank's passes
@@ -167,12 +195,16 @@ class RenderJob:
     # ---- RenderJob.cs:69-126 -------------------------------------------------------------------------------------
     def RenderInternal(self):
         first, n, stride = shard_passes(self.RenderOptions.Passes, self.rank, self.world_size)
-        self.RenderPasses(first, n, stride)
+        try:
+            self.RenderPasses(first, n, stride)
+        except OperationCanceledError:
+            self.Cancelled = True        # RenderJob.cs:114-118: the reference logs, leaves the pass loop and lets the task complete
         if self.world_size > 1:
             self.ReduceToRoot()
         if self.rank == 0:
-            self.UpdateImage(total_samples=self.RenderOptions.Passes if self.world_size > 1 else None)
-        self.UpdateStats()
+            # (after a cancel the ranks may have rendered different numbers of passes: resolve with what was rendered)
+            self.UpdateImage(total_samples=self._reduced_passes if self.world_size > 1 else None)
+        self.UpdateStats(reduce=self.world_size > 1)
         self.RenderCompleted = True
 
     def RenderPasses(self, first_pass: int, n_passes: int, stride: int = 1):
@@ -182,6 +214,7 @@ class RenderJob:
         done = 0
         while done < n_passes:
             if self._cancel.is_set():
+                self._passes_done += done
                 raise OperationCanceledError("render cancelled")
             m = min(chunk, n_passes - done)
             capi.check(self._lib.rt_render_passes(self.handle, first_pass + done * stride, m, stride))
@@ -190,8 +223,13 @@ class RenderJob:
         self._passes_done += n_passes
 
     def ReduceToRoot(self):
+        """The one exchange step: sum-reduce the colour sums (and the pass counts) to rank 0 — RCCL over xGMI on device tensors."""
+        import torch
         import torch.distributed as dist
         dist.reduce(self._accum_tensor, dst=0, op=dist.ReduceOp.SUM, group=self.process_group)
+        n = torch.tensor([self._passes_done], dtype=torch.int64, device=self._accum_tensor.device)
+        dist.reduce(n, dst=0, op=dist.ReduceOp.SUM, group=self.process_group)
+        self._reduced_passes = int(n.item())
 
     # ---- RenderJob.cs:646-654, 679-688 ---------------------------------------------------------------------------
     def UpdateImage(self, total_samples: Optional[int] = None):
@@ -215,9 +253,20 @@ class RenderJob:
         capi.check(self._lib.rt_render_read_accum(self.handle, buf.ctypes.data, C.byref(n)))
         return buf, int(n.value)
 
-    def UpdateStats(self) -> RenderStats:
+    def UpdateStats(self, reduce: bool = False) -> RenderStats:
+        """RenderStats from the device counters.  reduce=True (all ranks must call): the counters of every rank summed onto rank 0,
+        so that rank 0's RenderStats describes the whole job as the reference's single RenderStats does."""
         st = capi.Stats()
         capi.check(self._lib.rt_render_stats(self.handle, C.byref(st)))
+        if reduce and self.world_size > 1:
+            import torch
+            import torch.distributed as dist
+            dev = self._accum_tensor.device
+            raw = np.frombuffer(bytes(st), dtype=np.uint64).astype(np.int64)
+            t = torch.from_numpy(raw.copy()).to(dev)
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=self.process_group)
+            if self.rank == 0:
+                C.memmove(C.byref(st), t.cpu().numpy().astype(np.uint64).tobytes(), C.sizeof(st))
         s = self.RenderStats
         s.PixelsRendered, s.PassesRendered = st.pixels_rendered, st.passes_rendered
         s.MaterialScatterCount, s.MaterialAbsorbedCount = st.material_scatter_count, st.material_absorbed_count

@@ -105,6 +105,40 @@ def secondary_rays(flat, n, rs):
 NO_HIT = 0xFFFFFFFF
 
 
+def shadow_ray_set(scene, flat, orc, n, seed):
+    """Any-hit rays of the three kinds a render meets: camera rays and incoherent rays with random ranges, and (half of the set) rays
+    that start on a surface — the oracle's closest hit of an incoherent ray — and aim at a light (or, without lights, at a random
+    point of the scene) with SimpleLightBase's range [0.01, distance - 0.01].  Returns origins, directions, kMin, kMax."""
+    rs = np.random.default_rng(seed)
+    q = n // 4
+    o1, d1 = camera_rays(scene, 64, 64, q, rs)
+    o2, d2 = secondary_rays(flat, q, rs)
+    kmin12 = np.full(2 * q, 0.01, np.float32)
+    kmax12 = rs.uniform(0.1, 40.0, 2 * q).astype(np.float32)
+    # surface points
+    m = n - 2 * q
+    oo, dd = secondary_rays(flat, 3 * m, rs)
+    hits = orc.trace_closest(oo, dd, 0.001, np.inf, seed=seed)
+    ok = np.nonzero(hits["object"] != NO_HIT)[0][:m]
+    p = hits["world_point"][ok].astype(np.float32)
+    if len(p) < m:                                    # scenes where few rays hit anything: fill up with incoherent origins
+        p = np.concatenate([p, oo[:m - len(p)]])
+    if scene.Lights:
+        lp = np.array([l.Position for l in scene.Lights], np.float32)
+        tgt = lp[rs.integers(0, len(lp), m)] + rs.normal(scale=0.3, size=(m, 3)).astype(np.float32)
+    else:
+        mn, mx = scene_bounds(flat)
+        tgt = (mn + rs.random((m, 3), dtype=np.float32) * (mx - mn)).astype(np.float32)
+    v = (tgt - p).astype(np.float32)
+    dist = np.linalg.norm(v, axis=1).astype(np.float32)
+    dist = np.maximum(dist, 1e-3)
+    d3 = (v / dist[:, None]).astype(np.float32)
+    o = np.concatenate([o1, o2, p]); d = np.concatenate([d1, d2, d3])
+    kmin = np.concatenate([kmin12, np.full(m, 0.01, np.float32)])
+    kmax = np.concatenate([kmax12, (dist - np.float32(0.01)).astype(np.float32)])
+    return o, d, kmin, kmax
+
+
 def assert_closest_parity(g, r, max_near_ties=1e-4):
     """BASELINE north_star check 1: object and material ids bit-exact, K within 1e-5 relative; rays whose two nearest candidates
     lie within 1e-5 relative of each other are listed and excluded.  Such a ray exists when binary32 cancellation makes

@@ -34,11 +34,14 @@ def test_struct_sizes_match_header():
         assert int(sizes[name]) == C.sizeof(ct), name
 
 
+OPT_FIELDS = ["seed", "device", "stream", "accum_device", "flags", "max_passes_per_call", "n_devices", "device_ids"]
+
+
 def test_field_offsets_of_scene_desc_and_opts():
     fields = ["camera", "skybox", "objects", "spheres", "materials", "lights"]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "rt_hip.h"\nint main(void){\n' + "".join(
         f'printf("{f} %zu\\n", offsetof(rt_scene_desc, {f}));\n' for f in fields) + "".join(
-        f'printf("o_{f} %zu\\n", offsetof(rt_render_opts, {f}));\n' for f in ["seed", "device", "stream", "accum_device"]) + "return 0;}\n"
+        f'printf("o_{f} %zu\\n", offsetof(rt_render_opts, {f}));\n' for f in OPT_FIELDS) + "return 0;}\n"
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
         open(c, "w").write(src)
@@ -46,7 +49,7 @@ def test_field_offsets_of_scene_desc_and_opts():
         out = dict(l.split() for l in subprocess.check_output([exe], text=True).strip().splitlines())
     for f in fields:
         assert int(out[f]) == getattr(capi.SceneDesc, f).offset, f
-    for f in ["seed", "device", "stream", "accum_device"]:
+    for f in OPT_FIELDS:
         assert int(out["o_" + f]) == getattr(capi.RenderOpts, f).offset, f
 
 

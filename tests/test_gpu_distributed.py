@@ -29,12 +29,13 @@ def _worker(rank, world, port, out_path):
     opt = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=PASSES, MaxBounceDepth=6, Seed=4242)
     job = rt.RenderJob(sc, opt, device=0, rank=rank, world_size=world)
     job.Wait()                                   # RenderInternal: own passes -> ReduceToRoot -> (rank 0) resolve
-    st = job.RenderStats
-    px = torch.tensor([st.PixelsRendered], dtype=torch.int64)
-    dist.reduce(px, dst=0)
+    st = job.RenderStats                         # RenderInternal sum-reduced every rank's counters onto rank 0 (UpdateStats(reduce=True))
+    own = job._passes_done * W * H
     if rank == 0:
         acc = job._accum_tensor.cpu().numpy().reshape(H, W, 3)
-        np.savez(out_path, acc=acc, img=job.Image, pixels=px.numpy())
+        np.savez(out_path, acc=acc, img=job.Image, pixels=np.array([st.PixelsRendered]), rays=np.array([st.RayCount]), passes=np.array([st.PassesRendered]))
+    else:
+        assert st.PixelsRendered == own          # the other ranks keep their own counts
     dist.barrier()
     job.Dispose()
     dist.destroy_process_group()
@@ -50,7 +51,8 @@ def test_two_ranks_reduce_to_the_single_process_image(tmp_path):
     job = rt.RenderJob(rt.BuiltinScenes.Testing(), opt); job.Wait()
     ref, n = job.ReadAccum()
     got = np.load(out)
-    assert int(got["pixels"][0]) == W * H * PASSES == job.RenderStats.PixelsRendered
+    assert int(got["pixels"][0]) == W * H * PASSES == job.RenderStats.PixelsRendered       # rank 0's RenderStats describes the whole job
+    assert int(got["rays"][0]) == job.RenderStats.RayCount and int(got["passes"][0]) == PASSES
     assert np.allclose(got["acc"], ref, rtol=1e-5, atol=1e-6)
     assert (np.abs(got["img"].astype(int) - job.Image.astype(int)) <= 1).all()
     job.Dispose()

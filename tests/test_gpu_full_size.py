@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 NO_HIT = 0xFFFFFFFF
 
 
-def _ray_parity(sc, flat, dev, orc, n_closest, n_any, seed):
+def _ray_parity(sc, flat, dev, orc, n_closest, n_list, seed, n_any=120_000):
     rs = np.random.default_rng(seed)
     o1, d1 = helpers.camera_rays(sc, 64, 64, n_closest, rs)
     o2, d2 = helpers.secondary_rays(flat, n_closest, rs)
@@ -33,12 +33,35 @@ def _ray_parity(sc, flat, dev, orc, n_closest, n_any, seed):
     helpers.assert_closest_parity(g, r)
     hit = r["object"] != NO_HIT
     assert hit.sum() > n_closest // 4
-    # any-hit: the oracle scans every object per ray (the reference has no culling for shadow rays), so fewer rays
-    oa, da = np.concatenate([o1[:n_any], o2[:n_any]]), np.concatenate([d1[:n_any], d2[:n_any]])
-    kmin = np.full(len(oa), 0.01, np.float32)
-    kmax = rs.uniform(0.5, 40.0, len(oa)).astype(np.float32)
-    assert np.array_equal(dev.TraceAny(oa, da, kmin, kmax), orc.trace_any(oa, da, kmin, kmax))
+    # Any-hit.  The reference asks every object for every shadow ray (RenderJob.cs:575, BinaryBvhNode.cs:41): seconds per ray on these
+    # scenes.  So (1) the oracle's every-object scan and its culled form (oracle.cpp CullTree) are compared on n_list rays of THIS scene
+    # (tests/test_oracle_culled_any.py does it with 100 k rays on every small scene), then (2) the device answers n_any (>= 100 k)
+    # rays of the kinds a render traces — camera rays, incoherent rays, rays from surface points towards the lights — against the
+    # culled form, bit for bit, through k_trace_any.
+    oa, da, kmin, kmax = helpers.shadow_ray_set(sc, flat, orc, n_any, seed + 100)
+    ref = orc.trace_any(oa, da, kmin, kmax, threads=16, culled=True)
+    sub = rs.choice(len(oa), n_list, replace=False)
+    assert np.array_equal(orc.trace_any(oa[sub], da[sub], kmin[sub], kmax[sub], threads=16), ref[sub])
+    got = dev.TraceAny(oa, da, kmin, kmax)
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} of {len(ref)} any-hit answers differ from the oracle's"
+    assert 0.02 < ref.mean() < 0.98
     return int(hit.sum())
+
+
+def _render_vs_culled_oracle(sc, dev_flat, orc, opt, min_close, monkeypatch):
+    """An image at a size the oracle can only afford with culled shadow rays, in exact-lights mode (every shadow ray bit-identical),
+    through the shadow kernel the host would pick AND through the other one (RT_HIP_PERSISTENT_SHADOW forced off / on)."""
+    orc.set_culled_any(True)
+    ref, rst = orc.render(opt, threads=16)
+    orc.set_culled_any(False)
+    for forced in ("0", "1"):
+        monkeypatch.setenv("RT_HIP_PERSISTENT_SHADOW", forced)
+        dev = rt.DeviceScene(dev_flat)
+        monkeypatch.delenv("RT_HIP_PERSISTENT_SHADOW")
+        job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); st = job.RenderStats; job.Dispose(); dev.Dispose()
+        close = _image_close(got, ref)
+        assert close >= min_close, f"persistent shadow kernel {forced}: only {close:.5f} of pixels match"
+        assert (st.RayCount, st.ShadowRays) == (rst["ray_count"], rst["shadow_rays"])
 
 
 def _image_close(got, ref):
@@ -82,11 +105,14 @@ def _properties(sc, dev, opt):
 def test_config2_night_spheres_1080p():
     sc = bs.Testing(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
     assert dev.Info()["variant"] == "spheres" and dev.Info()["tree_in_lds"]
-    _ray_parity(sc, flat, dev, orc, 100_000, 2_000, 21)
+    _ray_parity(sc, flat, dev, orc, 100_000, 20_000, 21)
     opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=10, LightSampleCountHint=2, Seed=0xC2)
     got, st = _properties(sc, dev, opt)
     ref, rst = orc.render(opt, threads=16)
-    assert _image_close(got, ref) > 0.98
+    assert _image_close(got, ref) > 0.99
+    opt_x = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=10, LightSampleCountHint=2, Seed=0xC2, ExactLightSampling=True)
+    job = rt.RenderJob(sc, opt_x, device_scene=dev); job.Wait(); gx, _ = job.ReadAccum(); job.Dispose()
+    assert _image_close(gx, ref) >= 0.999                                         # 2 M pixels, every shadow ray identical to the oracle's
     assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] and abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"]
 
 
@@ -94,7 +120,7 @@ def test_config2_night_spheres_1080p():
 def test_config3_cornell_depth32_1080p(intensity, direct):
     sc = bs.CornellBox(intensity, direct); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
     assert dev.Info()["variant"] == "boxes" and dev.Info()["object_list"]
-    _ray_parity(sc, flat, dev, orc, 50_000, 5_000, 22)
+    _ray_parity(sc, flat, dev, orc, 50_000, 20_000, 22)
     opt = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=32, LightSampleCountHint=2, Seed=0xC3)
     got, st = _properties(sc, dev, opt)
     assert st.RayDepthCounts[32] > 0                                             # dielectric paths do reach the bounce limit
@@ -104,7 +130,7 @@ def test_config3_cornell_depth32_1080p(intensity, direct):
     assert _image_close(g, ref) > 0.97
 
 
-def test_config4_five_million_triangles():
+def test_config4_five_million_triangles(monkeypatch):
     sc = bs.TriangleMesh(); flat = flatten_scene(sc)
     assert flat.n_objects == 4_999_122
     dev = rt.DeviceScene(flat)
@@ -129,7 +155,7 @@ def test_config4_five_million_triangles():
     assert (np.abs(g["world_point"][:, 1]) < 1.2).all() and np.allclose(g["k"], 50.0 - g["world_point"][:, 1], atol=1e-4)
     # (2) the oracle on the full mesh
     orc = ob.OracleScene(flat)
-    _ray_parity(sc, flat, dev, orc, 20_000, 10, 23)
+    _ray_parity(sc, flat, dev, orc, 20_000, 300, 23)
     # (3) 4K image properties, and the oracle at a size it can afford
     opt = RenderOptions(RenderWidth=3840, RenderHeight=2160, Passes=2, MaxBounceDepth=8, LightSampleCountHint=2, Seed=0xC4)
     _properties(sc, dev, opt)
@@ -138,12 +164,16 @@ def test_config4_five_million_triangles():
     job = rt.RenderJob(sc, opt_s, device_scene=dev); job.Wait(); gi, _ = job.ReadAccum(); job.Dispose()
     ref, _ = orc.render(opt_s, threads=16)
     assert _image_close(gi, ref) > 0.95
+    # with culled shadow rays the oracle affords a real picture of the mesh: 480 x 270, depth 8, both shadow kernels
+    dev.Dispose()
+    _render_vs_culled_oracle(sc, flat, orc, RenderOptions(RenderWidth=480, RenderHeight=270, Passes=2, MaxBounceDepth=8, LightSampleCountHint=2, Seed=0xC4,
+                                                          ExactLightSampling=True), 0.999, monkeypatch)
 
 
-def test_config5_hundred_thousand_spheres_64_lights():
+def test_config5_hundred_thousand_spheres_64_lights(monkeypatch):
     sc = bs.ManySpheresManyLights(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
     assert flat.n_objects >= 100_000 and flat.n_lights == 64 and dev.Info()["variant"] == "spheres" and not dev.Info()["tree_in_lds"]
-    _ray_parity(sc, flat, dev, orc, 50_000, 1_000, 24)
+    _ray_parity(sc, flat, dev, orc, 50_000, 3_000, 24)
     opt = RenderOptions(RenderWidth=3840, RenderHeight=2160, Passes=1, MaxBounceDepth=10, LightSampleCountHint=1, Seed=0xC5, PassesPerBatch=1)
     job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
     a, n = job.ReadAccum(); st = job.RenderStats
@@ -156,6 +186,10 @@ def test_config5_hundred_thousand_spheres_64_lights():
     j = rt.RenderJob(sc, opt_s, device_scene=dev); j.Wait(); g, _ = j.ReadAccum(); j.Dispose()
     ref, _ = orc.render(opt_s, threads=16)
     assert _image_close(g, ref) > 0.95
+    # with culled shadow rays: 320 x 180 at the configured depth (64 shadow rays per hit: 30 M of them), both shadow kernels
+    dev.Dispose()
+    _render_vs_culled_oracle(sc, flat, orc, RenderOptions(RenderWidth=320, RenderHeight=180, Passes=2, MaxBounceDepth=10, LightSampleCountHint=1, Seed=0xC5,
+                                                          ExactLightSampling=True), 0.999, monkeypatch)
 
 
 def test_check1_two_million_rays_night_spheres():

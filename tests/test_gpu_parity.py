@@ -81,40 +81,75 @@ def test_edge_rays(pairs):
     assert dev.TraceClosest(np.zeros((0, 3)), np.zeros((0, 3))).shape == (0,)          # empty input
 
 
-@pytest.mark.parametrize("name,w,h,passes,depth,ls", [("Demo", 96, 54, 8, 8, 2), ("Testing", 96, 54, 8, 10, 2), ("CornellBox", 64, 64, 8, 32, 2),
-                                                      ("Zoo", 64, 36, 8, 6, 1), ("MiniMesh", 64, 36, 4, 8, 2), ("MiniManyLights", 64, 36, 4, 10, 1),
-                                                      ("Empty", 16, 9, 2, 3, 1), ("RgbSpheres", 64, 36, 4, 10, 2), ("Noise", 96, 54, 6, 8, 2)])
-def test_image_parity(pairs, name, w, h, passes, depth, ls):
+IMAGE_CASES = [("Demo", 96, 54, 8, 8, 2), ("Testing", 96, 54, 8, 10, 2), ("CornellBox", 64, 64, 8, 32, 2), ("Zoo", 64, 36, 8, 6, 1), ("MiniMesh", 64, 36, 4, 8, 2),
+               ("MiniManyLights", 64, 36, 4, 10, 1), ("Empty", 16, 9, 2, 3, 1), ("RgbSpheres", 64, 36, 4, 10, 2), ("Noise", 96, 54, 6, 8, 2)]
+
+
+def _worst(got, ref, fin, k=5):
+    """The k pixels farthest from the oracle: [(y, x, relative error, got rgb, ref rgb)] — printed by the image tests so that an
+    outlier is looked at, not just counted."""
+    rel = (np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)).max(axis=2)
+    rel[~fin] = 0
+    idx = np.argsort(rel.ravel())[::-1][:k]
+    H, W = rel.shape
+    return [(int(i // W), int(i % W), float(rel.ravel()[i]), got.reshape(-1, 3)[i].round(5).tolist(), ref.reshape(-1, 3)[i].round(5).tolist()) for i in idx]
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["hardware-ulp-lights", "exact-lights"])
+@pytest.mark.parametrize("name,w,h,passes,depth,ls", IMAGE_CASES)
+def test_image_parity(pairs, name, w, h, passes, depth, ls, exact):
+    """Check 2, path by path: the same RNG keys and the same one-rounding-per-operator arithmetic on both sides.
+    exact-lights (RT_RENDER_EXACT_LIGHT_SAMPLING): every shadow ray is bit-identical to the oracle's, so what is left is libm ulps
+    (sin/cos/pow/log/acos) and the forward-throughput vs reverse-pass association of the colour sums: >= 99.9 % of the pixels within
+    1e-3 relative (observed: all of them, largest error ~2e-6).
+    hardware-ulp-lights (the default): a shadow ray that grazes an occluder within the 1-ulp difference of v_rsq/v_rcp may fall the
+    other way, which changes a pixel by one light sample; >= 99 % of the pixels within 1e-3, and no pixel off by more than the light
+    all its samples can receive (every light, every sample, every pass: passes x sum of the lights' brightest channel)."""
     sc, flat, dev, orc = pairs(name)
-    opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234)
+    opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234, ExactLightSampling=exact)
     job = rt.RenderJob(sc, opt, device_scene=dev)
     job.Wait()
     got, n = job.ReadAccum()
     assert n == passes
     ref, rst = orc.render(opt, threads=8)
-    # Same RNG keys and the same one-rounding-per-operator arithmetic: almost every path is identical and differs only
-    # by libm (sin/cos/pow/log/acos) ulps and the forward-throughput vs reverse-pass association of the colour sums.
     fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
     assert fin.mean() > 0.999
     err = np.abs(got - ref)[fin]
     scale = np.maximum(np.abs(ref)[fin], 1e-3)
     close = (err <= 1e-3 * scale + 1e-5).all(axis=1).mean()
-    assert close > 0.97, f"only {close:.4f} of pixels match the oracle's sums"
+    worst = _worst(got, ref, fin)
+    print(f"{name} exact={exact}: {close:.5f} of pixels within 1e-3; max abs error {err.max(initial=0):.3g}; worst 5 (y, x, rel, got, ref): {worst}")
+    if exact:
+        assert close >= 0.999, f"only {close:.5f} of pixels match the oracle's sums in exact-lights mode; worst: {worst}"
+    else:
+        assert close >= 0.99, f"only {close:.5f} of pixels match the oracle's sums; worst: {worst}"
+        one_light_sample = passes * sum(float(np.max(np.abs(l.Colour.v))) for l in sc.Lights) if sc.Lights else 0.0
+        assert err.max(initial=0) <= one_light_sample * 1.001 + 1e-3 * float(np.abs(ref[fin]).max(initial=0)) + 1e-5, f"an outlier beyond what light sampling can explain: {worst}"
     for c in range(3):
         m_ref, m_got = ref[fin][:, c].mean(), got[fin][:, c].mean()
         assert abs(m_got - m_ref) <= 0.005 * max(abs(m_ref), 1e-6) + 1e-6, f"channel {c}: {m_got} vs {m_ref}"
     # tonemapped bytes
     img = job.Image
     ref_img = ob.resolve_rgb24(ref, passes)
-    assert (np.abs(img.astype(int) - ref_img.astype(int)) <= 2).mean() > 0.97
+    assert (np.abs(img.astype(int) - ref_img.astype(int)) <= 2).mean() > (0.999 if exact else 0.98)
     # stats: identical definitions on both sides
     st = job.RenderStats
     assert st.PixelsRendered == w * h * passes == rst["pixels_rendered"]
     assert st.PassesRendered == passes
+    if exact:
+        assert (st.RayCount, st.ShadowRays, st.MaterialScatterCount) == (rst["ray_count"], rst["shadow_rays"], rst["material_scatter_count"])
     assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] + 2
     assert abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"] + 2
     assert st.SkyRays + st.BounceLimitExceeded == st.PixelsRendered
     assert abs(sum(st.RayDepthCounts) - sum(rst["ray_depth_counts"])) <= 0.002 * st.PixelsRendered + 2      # RenderJob.cs:458
+    # the reference's three BVH counters (RenderStats.cs; BinaryBvhNode.cs:18, SingleObjectBvhNode.cs:15,23,28): every TryHit call either
+    # intersects or misses, and a failed box test is one of the box tests.  (The counts themselves depend on the tree's topology,
+    # which is implementation-defined in the reference, so they are not compared with the oracle's.)
+    assert st.HittableIntersections + st.HittableMisses == st.PrimTests
+    assert st.AabbMisses <= st.NodeVisits
+    if st.RayCount and name != "Empty":
+        assert st.HittableIntersections >= st.MaterialScatterCount and st.HittableIntersections > 0
+        assert (st.AabbMisses > 0) == (st.NodeVisits > 0) or st.NodeVisits == 0
     job.Dispose()
 
 
@@ -316,3 +351,67 @@ def test_kernel_choices_do_not_show_in_the_image(pairs, knob, value, monkeypatch
     if knob == "RT_HIP_VARIANT": assert info["variant"] == "generic"
     b = rt.RenderJob(sc, opt, device_scene=dev); b.Wait(); ib = b.ReadAccum()[0]; b.Dispose(); dev.Dispose()
     assert np.array_equal(ia, ib, equal_nan=True)
+
+
+def test_several_shards_inside_the_library(pairs):
+    """rt_render_opts.n_devices > 1 (SURVEY 8b / 8e inside the C ABI): the library replicates the scene by peer copies, shards every
+    call's passes over the devices (pass i of the call -> device i mod G, one host thread each) and combines the sums on device_ids[0].
+    The 1-GPU box names the same card twice or three times: two / three shards, scene replicas and the gather-and-add all run.
+    Equal to the one-device image up to float-sum association; statistics are the shards' sums."""
+    sc, flat, dev, orc = pairs("Testing")
+    opt = RenderOptions(RenderWidth=160, RenderHeight=90, Passes=7, MaxBounceDepth=8, LightSampleCountHint=2, Seed=4711)
+    one = rt.RenderJob(sc, opt, device_scene=dev); one.Wait(); a, n1 = one.ReadAccum(); st1 = one.RenderStats; img1 = one.Image.copy(); one.Dispose()
+    for devices in ([0, 0], [0, 0, 0]):
+        job = rt.RenderJob(sc, opt, device_scene=dev, devices=devices)
+        job.passes_per_call = 4                                  # two calls: 4 passes, then 3 (a ragged split over the shards)
+        job.Wait()
+        b, n = job.ReadAccum(); st = job.RenderStats
+        assert n == n1 == 7 and st.PassesRendered == 7
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+        assert (st.PixelsRendered, st.RayCount, st.ShadowRays, st.MaterialScatterCount, st.NodeVisits, st.AabbMisses) == \
+               (st1.PixelsRendered, st1.RayCount, st1.ShadowRays, st1.MaterialScatterCount, st1.NodeVisits, st1.AabbMisses)
+        assert st.RayDepthCounts == st1.RayDepthCounts
+        assert (np.abs(job.Image.astype(int) - img1.astype(int)) <= 1).all()
+        job.Dispose()
+    # shard g of G renders passes g, g + G, ...: two shards are exactly the two halves a two-process job would render
+    halves = []
+    for r in range(2):
+        j = rt.RenderJob(sc, opt, device_scene=dev); j.RenderPasses(*rt.shard_passes(7, r, 2)); halves.append(j.ReadAccum()[0]); j.Dispose()
+    job = rt.RenderJob(sc, opt, device_scene=dev, devices=[0, 0]); job.Wait(); b, _ = job.ReadAccum(); job.Dispose()
+    assert np.array_equal(b, halves[0] + halves[1])             # shard 0's sums + shard 1's, added once, in shard order
+    # rejected combinations
+    import ctypes as C
+    from raytracer_amd import capi
+    lib = capi.load(); h = C.c_void_p()
+    bad = rt.render_job.make_opts(opt, devices=[0, 99])
+    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -1 and b"out of range" in lib.rt_last_error()
+    bad = rt.render_job.make_opts(opt, devices=[0, 0]); bad.stream = 1
+    assert lib.rt_render_create(dev.handle, C.byref(bad), C.byref(h)) == -1
+
+
+def test_a_scene_outlives_its_renders_or_says_so(pairs):
+    """rt_scene_destroy while a render still uses the scene is refused (every rt_render_* call reads the scene's device tables)."""
+    from raytracer_amd import capi
+    sc = helpers.small_scenes()["Sphere"]()
+    dev = rt.DeviceScene(sc)
+    job = rt.RenderJob(sc, RenderOptions(RenderWidth=16, RenderHeight=16, Passes=1), device_scene=dev)
+    lib = capi.load()
+    assert lib.rt_scene_destroy(dev.handle) == -1 and b"still use" in lib.rt_last_error()
+    dev.Dispose()                                                # refused: the handle stays valid
+    job.Wait()
+    assert job.Image.any()
+    job.Dispose()
+    dev.Dispose()
+    assert not dev.handle
+
+
+def test_a_debug_visualisation_of_a_scene_without_media_has_no_shader_data_to_read(pairs):
+    """The visualisation kernel is the generic one (it knows ConstantDensityMedium's ShaderData), whatever variant the scene itself
+    got; a render of a scene without media allocates no ShaderData array, and the kernel must not touch it."""
+    for name in ("Testing", "CornellBox", "MiniMesh"):
+        sc, flat, dev, orc = pairs(name)
+        assert dev.Info()["variant"] != "generic"
+        opt = RenderOptions(RenderWidth=64, RenderHeight=36, Passes=2, MaxBounceDepth=4, Seed=3, DebugVisualisation=1)
+        job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); job.Dispose()
+        ref, _ = orc.render(opt, threads=4)
+        assert (np.abs(got - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2) + 1e-5).all(axis=2).mean() > 0.985
