@@ -170,7 +170,9 @@ SYMBOLS = {
     "rt_render_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile)]),
     "rt_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "rt_trace_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rt_trace_closest_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
 }
+RT_TRACE_NOALLOC_MAX_RAYS = 1 << 17
 
 
 class RtError(RuntimeError):

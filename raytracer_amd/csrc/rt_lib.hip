@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -191,6 +192,28 @@ void collect_stamps(rt_render* r) {       // call after the stream has been sync
 }
 } // namespace
 
+// rt_trace_closest for callers that cannot allocate (rt_hip.h): the device copies of the rays and of the hit records live in a
+// file-scope device array instead of two hipMalloc'ed buffers.  `scratch` is only a host-side stand-in for the symbol: the address
+// the kernels and copies use is resolved once per device with hipGetSymbolAddress (scratch_for_device, called by rt_scene_create with
+// that device current) and kept in g_scratch[device]; each GPU has its own copy of the array at its own address.
+static __device__ __align__(256) unsigned char scratch[RT_TRACE_NOALLOC_MAX_RAYS * (sizeof(rt_ray) + sizeof(rt_hit))];
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+// the current device must be `device`
+int scratch_for_device(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(RT_ERR_INVALID_ARG, "device %d beyond the %d this library keeps scratch for", device, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch[device]) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    g_scratch[device] = p;
+    return RT_OK;
+}
+} // namespace
+
 extern "C" {
 
 int rt_version(void) { return RT_ABI_VERSION; }
@@ -355,6 +378,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (device >= ndev) return fail(RT_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
+    if (int src = scratch_for_device(device)) return src;      // rt_trace_closest_noalloc's array on this device (once per device)
 
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = ks;
@@ -491,6 +515,7 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     *out = nullptr;
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
+    if (int rc = scratch_for_device(device)) return rc;
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
     s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->persistent = src->persistent;
@@ -575,6 +600,26 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, dout, n, hipMemcpyDeviceToHost));
     trace_release_large(s);
+    return RT_OK;
+}
+
+int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits) {
+    if (!s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_trace_closest_noalloc: null argument");
+    if (n > RT_TRACE_NOALLOC_MAX_RAYS) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest_noalloc: %llu rays, at most %u per call (use rt_trace_closest, which allocates)", (unsigned long long)n, (unsigned)RT_TRACE_NOALLOC_MAX_RAYS);
+    if (!n) return RT_OK;
+    void* base = nullptr;
+    { std::lock_guard<std::mutex> lock(g_scratch_mutex); base = g_scratch[s->device]; }     // resolved by rt_scene_create on this device
+    if (!base) return fail(RT_ERR_HIP, "rt_trace_closest_noalloc: no scratch address for device %d", s->device);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", s->device);
+    // [rays: MAX x rt_ray][hits: MAX x rt_hit]; every hit record of 0..n-1 is written by the kernel, nothing has to start at zero
+    rt_ray* d_rays = (rt_ray*)base;
+    rt_hit* d_hits = (rt_hit*)((unsigned char*)base + (size_t)RT_TRACE_NOALLOC_MAX_RAYS * sizeof(rt_ray));
+    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
+    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost));       // (null stream: ordered after the kernel, blocks until the copy is done)
     return RT_OK;
 }
 
