@@ -1,17 +1,20 @@
 // HipRenderBackend.cs — the reference-side binding of include/rt_hip.h (source only: this image has no .NET SDK,
-// so the file is not compiled here; the tested drivers of the same entry points are raytracer_amd/capi.py and tests/).
+// so the file is not compiled here; tests/test_csharp_binding.py checks every [StructLayout] struct and every
+// [DllImport] below against the header field by field, and the tested drivers of the same entry points are
+// raytracer_amd/capi.py and tools/rtbench.cpp).
 //
 // Where it goes: Ararem.RayTracer.Core/Backends/HipRenderBackend.cs.  RenderJob.RenderInternal (RenderJob.cs:69-126)
 // gets one new first line:
 //
 //     if (RenderOptions.Backend == RenderBackend.Hip) { new HipRenderBackend().Render(this, cancellationToken); return; }
 //
-// and RenderOptions one new init-only property `Backend` (default Cpu, or env RT_BACKEND=hip).  Nothing else in the
-// public surface changes: Image, ImageBuffer, RenderStats, RenderTask, StartOrGetRenderAsync keep their meaning.
+// and RenderOptions three new init-only properties: `Backend` (default Cpu, or env RT_BACKEND=hip), `Devices`
+// (HIP ordinals; default: one GPU) and `ExactLightSampling`.  Nothing else in the public surface changes: Image,
+// ImageBuffer, RenderStats, RenderTask, StartOrGetRenderAsync keep their meaning.
 //
 // Core cannot name Impl types (Impl -> Core, Ararem.RayTracer.Impl.csproj:23), so flattening is an interface the
-// builtin Impl classes implement; anything that does not implement it is rejected with NotSupportedException at
-// Render() time — there is no CPU fallback behind this backend.
+// builtin Impl classes implement (csharp/Impl/DeviceFlatteners.cs); anything that does not implement it is rejected
+// with NotSupportedException at Render() time — there is no CPU fallback behind this backend.
 using System;
 using System.Collections.Generic;
 using System.Runtime.CompilerServices;
@@ -23,39 +26,71 @@ namespace Ararem.RayTracer.Core.Backends;
 
 public enum RenderBackend { Cpu = 0, Hip = 1 }
 
-/// <summary>Implemented by every builtin Hittable / Material / Texture / Light / SkyBox in Ararem.RayTracer.Impl.</summary>
+/// <summary>What RenderJob.RenderInternal hands the pass loop to (RenderJob.cs:69): the CPU loop stays the default implementation.</summary>
+internal interface IRenderBackend
+{
+	/// <summary>Renders job.RenderOptions.Passes passes (or until cancelled) into job.Image / job.RenderStats.</summary>
+	void Render(RenderJob job, CancellationToken ct);
+}
+
+/// <summary>Implemented by every builtin Hittable / Material / Texture / Light in Ararem.RayTracer.Impl.</summary>
 public interface IDeviceFlattenable
 {
 	/// <summary>Appends this object's record(s) to the builder's tables and returns its index in its table.</summary>
 	uint Flatten(DeviceSceneBuilder builder);
 }
 
-internal static unsafe class RtHip
+/// <summary>Implemented by the Hittables: their table (rt_hittable_type) besides the index, so that ConstantDensityMedium and
+/// DiffuseShapedLight can refer to a shape that is not itself a scene object.</summary>
+public interface IDeviceHittable : IDeviceFlattenable
+{
+	/// <summary>rt_hittable_type of the record Flatten appends.</summary>
+	uint DeviceType { get; }
+}
+
+/// <summary>Implemented by DefaultSkyBox and SingleColourSkyBox.</summary>
+public interface IDeviceSkyBox { RtHip.SkyBox FlattenSkyBox(); }
+
+public static unsafe class RtHip
 {
 	private const string Lib = "rt_hip"; // librt_hip.so next to the assembly, or on LD_LIBRARY_PATH
 
-	public const uint AbiVersion = 1;
-	public const uint NoHit      = 0xFFFFFFFFu;
+	public const uint AbiVersion = 2;            // RT_ABI_VERSION
+	public const uint NoHit      = 0xFFFFFFFFu;  // RT_NO_HIT
+	public const int  MaxDevices = 16;           // RT_MAX_DEVICES
+	public const uint RenderExactLightSampling = 1u;   // RT_RENDER_EXACT_LIGHT_SAMPLING
+	public const uint TraceNoAllocMaxRays = 1u << 17;  // RT_TRACE_NOALLOC_MAX_RAYS
 
-	[StructLayout(LayoutKind.Sequential)] public struct Object  { public uint Type, Index, Material; public fixed float AabbMin[3]; public fixed float AabbMax[3]; }
+	// rt_hittable_type
+	public const uint HitSphere = 0, HitQuad = 1, HitTriangle = 2, HitInfinitePlane = 3, HitXyPlane = 4, HitXzPlane = 5, HitYzPlane = 6, HitDisk = 7, HitBox = 8,
+	                  HitCapsule = 9, HitCylinder = 10, HitMedium = 11;
+	// rt_texture_type, rt_material_type, rt_light_type, rt_attenuation_kind, rt_skybox_type
+	public const uint TexSolid = 0, TexMarble = 1, TexGreyscalePerlin = 2;
+	public const uint MatStandard = 0, MatRefractive = 1, MatEmissiveRefractive = 2, MatPhong = 3, MatVolumetric = 4;
+	public const uint MatFlagAlternateRefraction = 1u, MatFlagDirectEmission = 2u;
+	public const uint LightPoint = 0, LightDiffuseSphere = 1, LightDiffuseShaped = 2;
+	public const uint AttenConstant = 0, AttenLinear = 1, AttenPower = 2, AttenPowerStayHigh = 3, AttenLogistic = 4, AttenLogisticLkx = 5, AttenExpDecay = 6;
+	public const uint SkyDefault = 0, SkySingleColour = 1;
+
 	[StructLayout(LayoutKind.Sequential)] public struct Sphere  { public fixed float Centre[3]; public float Radius; }
 	[StructLayout(LayoutKind.Sequential)] public struct Quad    { public fixed float Origin[3]; public fixed float Normal[3]; public fixed float InvCol1[4]; public fixed float InvCol2[4]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Triangle{ public fixed float V0[3]; public fixed float E1[3]; public fixed float E2[3]; public fixed float Normal[3]; public fixed float InvCol1[4]; public fixed float InvCol2[4]; }
 	[StructLayout(LayoutKind.Sequential)] public struct InfinitePlane { public fixed float Point[3]; public fixed float Normal[3]; public float NegPointDotNormal; }
-	[StructLayout(LayoutKind.Sequential)] public struct AxisPlane { public float ALo, AHi, BLo, BHi, C; }
-	[StructLayout(LayoutKind.Sequential)] public struct Disk    { public fixed float Centre[3]; public fixed float Normal[3]; public float Radius, NegCentreDotNorm; public fixed float InvCol1[4]; public fixed float InvCol2[4]; }
+	[StructLayout(LayoutKind.Sequential)] public struct AxisPlane { public float ALo; public float AHi; public float BLo; public float BHi; public float C; }
+	[StructLayout(LayoutKind.Sequential)] public struct Disk    { public fixed float Centre[3]; public fixed float Normal[3]; public float Radius; public float NegCentreDotNorm; public fixed float InvCol1[4]; public fixed float InvCol2[4]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Box     { public fixed float WorldToBox[12]; public fixed float BoxToWorldRows[9]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Capsule { public fixed float P1[3]; public fixed float P2[3]; public float Radius; public fixed float UvMatrix[9]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Cylinder{ public fixed float P1[3]; public fixed float P2[3]; public float Radius; }
-	[StructLayout(LayoutKind.Sequential)] public struct Medium  { public uint BoundaryType, BoundaryIndex; public float Density, NegInvDensity; }
+	[StructLayout(LayoutKind.Sequential)] public struct Medium  { public uint BoundaryType; public uint BoundaryIndex; public float Density; public float NegInvDensity; }
+	[StructLayout(LayoutKind.Sequential)] public struct Object  { public uint Type; public uint Index; public uint Material; public fixed float AabbMin[3]; public fixed float AabbMax[3]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Texture { public uint Type; public fixed float F[7]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Material{ public uint Type; public fixed uint Tex[2]; public uint Flags; public fixed float F[10]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Light
 	{
 		public uint Type; public fixed float Position[3]; public fixed float Colour[3];
-		public float AttenuationRadius, CutoffRadius, DiffusionRadius;
+		public float AttenuationRadius; public float CutoffRadius; public float DiffusionRadius;
 		public uint AttenKind; public fixed float AttenP[3];
-		public uint ShapeType, ShapeIndex; public fixed float ShapeAabbMin[3]; public fixed float ShapeAabbMax[3];
+		public uint ShapeType; public uint ShapeIndex; public fixed float ShapeAabbMin[3]; public fixed float ShapeAabbMax[3];
 	}
 	[StructLayout(LayoutKind.Sequential)] public struct SkyBox  { public uint Type; public fixed float Colour[3]; }
 	[StructLayout(LayoutKind.Sequential)] public struct Camera
@@ -67,8 +102,8 @@ internal static unsafe class RtHip
 	[StructLayout(LayoutKind.Sequential)]
 	public struct SceneDesc
 	{
-		public uint StructSize, AbiVersion;
-		public Camera Camera; public SkyBox SkyBox;
+		public uint StructSize; public uint AbiVersion;
+		public Camera Camera; public SkyBox Skybox;
 		public uint NObjects;        public Object*        Objects;
 		public uint NSpheres;        public Sphere*        Spheres;
 		public uint NQuads;          public Quad*          Quads;
@@ -89,30 +124,41 @@ internal static unsafe class RtHip
 
 	/// <summary>rt_scene_info: what BvhTree's construction log lines report (Acceleration/BvhTree.cs:29-41), plus the kernel variant and tree placement</summary>
 	[StructLayout(LayoutKind.Sequential)]
-	public unsafe struct SceneInfo
+	public struct SceneInfo
 	{
-		public uint NObjects, NUnbounded, NNodes, BvhDepth, TreeInLds, LdsImageBytes, BuiltOnDevice, ObjectList;
+		public uint NObjects; public uint NUnbounded; public uint NNodes; public uint BvhDepth; public uint TreeInLds; public uint LdsImageBytes; public uint BuiltOnDevice; public uint ObjectList;
 		public fixed byte Variant[16];
 	}
 
 	[StructLayout(LayoutKind.Sequential)]
 	public struct RenderOpts
 	{
-		public uint StructSize, Width, Height;
-		public float KMin, KMax;
-		public uint MaxBounceDepth, LightSampleCountHint, DebugVisualisation;
+		public uint StructSize; public uint Width; public uint Height;
+		public float KMin; public float KMax;
+		public uint MaxBounceDepth; public uint LightSampleCountHint; public uint DebugVisualisation;
 		public ulong Seed;
 		public uint PassesPerBatch; public int Device;
 		public IntPtr Stream; public float* AccumDevice;
+		public uint Flags; public uint MaxPassesPerCall; public uint NDevices;
+		public fixed int DeviceIds[16];
 	}
 
 	[StructLayout(LayoutKind.Sequential)]
 	public struct Stats
 	{
-		public ulong PixelsRendered, PassesRendered, MaterialScatterCount, MaterialAbsorbedCount, AabbMisses, HittableMisses, HittableIntersections,
-		             SkyRays, BounceLimitExceeded, RayCount, ShadowRays, NodeVisits, PrimTests, ShadowNodeVisits, ShadowPrimTests;
+		public ulong PixelsRendered; public ulong PassesRendered; public ulong MaterialScatterCount; public ulong MaterialAbsorbedCount; public ulong AabbMisses;
+		public ulong HittableMisses; public ulong HittableIntersections; public ulong SkyRays; public ulong BounceLimitExceeded; public ulong RayCount;
+		public ulong ShadowRays; public ulong NodeVisits; public ulong PrimTests; public ulong ShadowNodeVisits; public ulong ShadowPrimTests;
 		public fixed ulong RayDepthCounts[64];
 	}
+
+	[StructLayout(LayoutKind.Sequential)] public struct Ray { public fixed float Origin[3]; public fixed float Direction[3]; }
+	[StructLayout(LayoutKind.Sequential)]
+	public struct Hit
+	{
+		public float K; public uint Object; public uint Material; public fixed float Normal[3]; public fixed float Uv[2]; public fixed float WorldPoint[3]; public uint OutsideFace;
+	}
+	[StructLayout(LayoutKind.Sequential)] public struct KernelProfile { public fixed ulong Launches[6]; public fixed double TotalMs[6]; }
 
 	[DllImport(Lib)] public static extern int    rt_version();
 	[DllImport(Lib)] public static extern IntPtr rt_last_error();
@@ -125,7 +171,13 @@ internal static unsafe class RtHip
 	[DllImport(Lib)] public static extern int    rt_render_passes(IntPtr render, ulong firstPass, uint nPasses, uint passStride);
 	[DllImport(Lib)] public static extern int    rt_render_read_rgb24(IntPtr render, byte* dst);
 	[DllImport(Lib)] public static extern int    rt_render_read_accum(IntPtr render, float* rgbSum, out uint sampleCount);
+	[DllImport(Lib)] public static extern int    rt_render_resolve_device(IntPtr render, float* accumDevice, uint sampleCount, byte* dstHost);
 	[DllImport(Lib)] public static extern int    rt_render_stats(IntPtr render, out Stats stats);
+	[DllImport(Lib)] public static extern int    rt_render_set_profiling(IntPtr render, int enable);
+	[DllImport(Lib)] public static extern int    rt_render_kernel_profile(IntPtr render, out KernelProfile profile);
+	[DllImport(Lib)] public static extern int    rt_trace_closest(IntPtr scene, Ray* rays, ulong n, float kMin, float kMax, ulong seed, Hit* hits);
+	[DllImport(Lib)] public static extern int    rt_trace_any(IntPtr scene, Ray* rays, float* kMin, float* kMax, ulong n, byte* occluded);
+	[DllImport(Lib)] public static extern int    rt_trace_closest_noalloc(IntPtr scene, Ray* rays, ulong n, float kMin, float kMax, ulong seed, Hit* hits);
 
 	public static void Check(int rc)
 	{
@@ -135,33 +187,37 @@ internal static unsafe class RtHip
 		{
 				-2 => new NotSupportedException(msg),     // RT_ERR_UNSUPPORTED: a type the kernels do not implement
 				-1 => new ArgumentException(msg),         // RT_ERR_INVALID_ARG
-				-5 => new OutOfMemoryException(msg),
+				-5 => new OutOfMemoryException(msg),      // RT_ERR_OUT_OF_MEMORY
+				-6 => new ArgumentOutOfRangeException(null, msg), // RT_ERR_TOO_LARGE
 				_  => new InvalidOperationException($"rt_hip error {rc}: {msg}")
 		};
 	}
+
+	public static void Put(float* dst, System.Numerics.Vector3 v) { dst[0] = v.X; dst[1] = v.Y; dst[2] = v.Z; }
+	public static void Put(float* dst, Colour c) { dst[0] = c.R; dst[1] = c.G; dst[2] = c.B; }
 }
 
 /// <summary>Collects the flattened tables.  Ids are assigned by object reference: RefractiveMaterial.cs:51-52 and
 /// EmissiveRefractiveMaterial.cs:53-63 compare materials with == / != on references, so two equal-valued materials stay distinct.</summary>
 public sealed unsafe class DeviceSceneBuilder
 {
-	internal readonly List<RtHip.Object> Objects = new();
-	internal readonly List<RtHip.Sphere> Spheres = new();
-	internal readonly List<RtHip.Quad> Quads = new();
-	internal readonly List<RtHip.Triangle> Triangles = new();
-	internal readonly List<RtHip.InfinitePlane> InfinitePlanes = new();
-	internal readonly List<RtHip.AxisPlane> XyPlanes = new(), XzPlanes = new(), YzPlanes = new();
-	internal readonly List<RtHip.Disk> Disks = new();
-	internal readonly List<RtHip.Box> Boxes = new();
-	internal readonly List<RtHip.Capsule> Capsules = new();
-	internal readonly List<RtHip.Cylinder> Cylinders = new();
-	internal readonly List<RtHip.Medium> Media = new();
-	internal readonly List<RtHip.Material> Materials = new();
-	internal readonly List<RtHip.Texture> Textures = new();
-	internal readonly List<RtHip.Light> Lights = new();
+	public readonly List<RtHip.Object> Objects = new();
+	public readonly List<RtHip.Sphere> Spheres = new();
+	public readonly List<RtHip.Quad> Quads = new();
+	public readonly List<RtHip.Triangle> Triangles = new();
+	public readonly List<RtHip.InfinitePlane> InfinitePlanes = new();
+	public readonly List<RtHip.AxisPlane> XyPlanes = new(), XzPlanes = new(), YzPlanes = new();
+	public readonly List<RtHip.Disk> Disks = new();
+	public readonly List<RtHip.Box> Boxes = new();
+	public readonly List<RtHip.Capsule> Capsules = new();
+	public readonly List<RtHip.Cylinder> Cylinders = new();
+	public readonly List<RtHip.Medium> Media = new();
+	public readonly List<RtHip.Material> Materials = new();
+	public readonly List<RtHip.Texture> Textures = new();
+	public readonly List<RtHip.Light> Lights = new();
 	private readonly Dictionary<object, uint> ids = new(ReferenceEqualityComparer.Instance);
 
-	/// <summary>Index of <paramref name="o"/> in its table, flattening it on first sight; rejects user-defined types.</summary>
+	/// <summary>Index of a Material / Texture in its table, flattening it on first sight (one entry per distinct REFERENCE); rejects user-defined types.</summary>
 	public uint IdOf(object o)
 	{
 		if (ids.TryGetValue(o, out uint id)) return id;
@@ -172,9 +228,19 @@ public sealed unsafe class DeviceSceneBuilder
 		return id;
 	}
 
-	/// <summary>One Scene.SceneObjects element: <paramref name="type"/>/<paramref name="index"/> name the record its Hittable appended.</summary>
-	public void AddObject(uint type, uint index, Material material, AxisAlignedBoundingBox aabb)
+	/// <summary>(rt_hittable_type, index) of a Hittable's primitive record; a shape used twice (scene object and light shape) gets one record.</summary>
+	public (uint type, uint index) Shape(Hittable h)
 	{
+		if (h is not IDeviceHittable d)
+			throw new NotSupportedException($"{h.GetType().FullName} has no device representation (user-defined Hittables are rejected by the HIP backend, not emulated)");
+		return (d.DeviceType, IdOf(h));
+	}
+
+	/// <summary>One Scene.SceneObjects element, in scene order: its index in Objects is the object id the kernels report.</summary>
+	public void AddObject(Hittable hittable, Material material)
+	{
+		(uint type, uint index) = Shape(hittable);
+		AxisAlignedBoundingBox aabb = hittable.BoundingVolume;
 		RtHip.Object o = new() { Type = type, Index = index, Material = IdOf(material) };
 		o.AabbMin[0] = aabb.Min.X; o.AabbMin[1] = aabb.Min.Y; o.AabbMin[2] = aabb.Min.Z;
 		o.AabbMax[0] = aabb.Max.X; o.AabbMax[1] = aabb.Max.Y; o.AabbMax[2] = aabb.Max.Z;
@@ -182,17 +248,26 @@ public sealed unsafe class DeviceSceneBuilder
 	}
 }
 
-internal sealed unsafe class HipRenderBackend
+internal sealed unsafe class HipRenderBackend : IRenderBackend
 {
-	/// <summary>Passes traced per rt_render_passes call: the cancellation and Image/RenderStats refresh granularity.</summary>
+	/// <summary>Passes traced per rt_render_passes call: the cancellation and Image/RenderStats refresh granularity.  Also given to the library as
+	/// max_passes_per_call, so that it keeps path state for this many passes per batch and not for its default of 64.</summary>
 	private const uint PassesPerCall = 8;
 
 	public void Render(RenderJob job, CancellationToken ct)
 	{
 		Scene scene = job.Scene; RenderOptions o = job.RenderOptions;
 		DeviceSceneBuilder b = new();
-		foreach (SceneObject so in scene.SceneObjects) b.IdOf(so.Hittable);   // each Hittable.Flatten calls b.AddObject(...)
+		foreach (SceneObject so in scene.SceneObjects)
+		{
+			// the Hittable's own Material (SingleMaterialHittable.Material, ConstantDensityMedium's internal VolumetricMaterial)
+			if (so.Hittable is not IDeviceHittable) throw new NotSupportedException($"{so.Hittable.GetType().FullName}: user-defined Hittables are rejected by the HIP backend");
+			b.AddObject(so.Hittable, DeviceMaterialOf(so.Hittable));
+		}
 		foreach (Light l in scene.Lights) b.IdOf(l);
+
+		int[] devices = o.Devices is { Length: > 0 } ? o.Devices : new[] { -1 };
+		if (devices.Length > RtHip.MaxDevices) throw new ArgumentOutOfRangeException(nameof(o.Devices), $"at most {RtHip.MaxDevices} devices");
 
 		IntPtr hScene = IntPtr.Zero, hRender = IntPtr.Zero;
 		RtHip.Object[] objs = b.Objects.ToArray(); RtHip.Sphere[] sph = b.Spheres.ToArray(); RtHip.Quad[] quads = b.Quads.ToArray(); RtHip.Triangle[] tris = b.Triangles.ToArray();
@@ -208,7 +283,7 @@ internal sealed unsafe class HipRenderBackend
 				RtHip.SceneDesc d = new()
 				{
 						StructSize = (uint)sizeof(RtHip.SceneDesc), AbiVersion = RtHip.AbiVersion,
-						Camera = FlattenCamera(scene.Camera), SkyBox = FlattenSky(scene.SkyBox),
+						Camera = FlattenCamera(scene.Camera), Skybox = FlattenSky(scene.SkyBox),
 						NObjects = (uint)objs.Length, Objects = pO, NSpheres = (uint)sph.Length, Spheres = pS, NQuads = (uint)quads.Length, Quads = pQ,
 						NTriangles = (uint)tris.Length, Triangles = pT, NInfinitePlanes = (uint)planes.Length, InfinitePlanes = pP,
 						NXyPlanes = (uint)xy.Length, XyPlanes = pXy, NXzPlanes = (uint)xz.Length, XzPlanes = pXz, NYzPlanes = (uint)yz.Length, YzPlanes = pYz,
@@ -216,22 +291,31 @@ internal sealed unsafe class HipRenderBackend
 						NCylinders = (uint)cyls.Length, Cylinders = pCy, NMedia = (uint)media.Length, Media = pM,
 						NMaterials = (uint)mats.Length, Materials = pMat, NTextures = (uint)texs.Length, Textures = pTex, NLights = (uint)lights.Length, Lights = pL
 				};
-				RtHip.Check(RtHip.rt_scene_create(&d, -1, out hScene));       // the library copies every table during the call
+				RtHip.Check(RtHip.rt_scene_create(&d, devices[0], out hScene));       // the library copies every table during the call
 			}
 			RtHip.RenderOpts ro = new()
 			{
 					StructSize = (uint)sizeof(RtHip.RenderOpts), Width = (uint)o.RenderWidth, Height = (uint)o.RenderHeight, KMin = o.KMin, KMax = o.KMax,
 					MaxBounceDepth = (uint)o.MaxBounceDepth, LightSampleCountHint = (uint)o.LightSampleCountHint, DebugVisualisation = (uint)o.DebugVisualisation,   // rt_debug_vis has the enum's values
-					Seed = (ulong)Random.Shared.NextInt64(), PassesPerBatch = 0, Device = -1, Stream = IntPtr.Zero, AccumDevice = null
+					Seed = (ulong)Random.Shared.NextInt64(), PassesPerBatch = 0, Device = -1, Stream = IntPtr.Zero, AccumDevice = null,
+					Flags = o.ExactLightSampling ? RtHip.RenderExactLightSampling : 0u,
+					MaxPassesPerCall = PassesPerCall * (uint)devices.Length,        // one call's passes are split over the devices
+					NDevices = devices.Length > 1 ? (uint)devices.Length : 0u
 			};
+			if (devices.Length > 1)
+			{
+				RtHip.SceneInfo _; RtHip.Check(RtHip.rt_scene_get_info(hScene, out _));
+				for (int i = 0; i < devices.Length; i++) ro.DeviceIds[i] = devices[i];   // device_ids[0] must be the scene's device: devices[0] above
+			}
 			RtHip.Check(RtHip.rt_render_create(hScene, &ro, out hRender));
 
+			uint perCall = PassesPerCall * (uint)devices.Length;
 			job.Stopwatch.Start();
 			for (ulong pass = 0; o.InfinitePasses || pass < o.Passes;)
 			{
 				if (ct.IsCancellationRequested) break;                           // RenderJob.cs:114-118: log and leave the loop, the task completes normally
-				uint n = o.InfinitePasses ? PassesPerCall : (uint)Math.Min(PassesPerCall, o.Passes - pass);
-				RtHip.Check(RtHip.rt_render_passes(hRender, pass, n, 1));
+				uint n = o.InfinitePasses ? perCall : (uint)Math.Min(perCall, o.Passes - pass);
+				RtHip.Check(RtHip.rt_render_passes(hRender, pass, n, 1));          // with n_devices > 1 the library shards these n passes over the GPUs
 				pass += n;
 				Publish(job, hRender);                                             // the GUIs poll Image / RenderStats at 30 Hz without locks (RenderBufferPanel.cs:53-79)
 			}
@@ -239,10 +323,18 @@ internal sealed unsafe class HipRenderBackend
 		}
 		finally
 		{
-			if (hRender != IntPtr.Zero) RtHip.rt_render_destroy(hRender);
+			if (hRender != IntPtr.Zero) RtHip.rt_render_destroy(hRender);          // renders before their scene: rt_scene_destroy refuses otherwise
 			if (hScene != IntPtr.Zero) RtHip.rt_scene_destroy(hScene);
 		}
 	}
+
+	/// <summary>The Material a Hittable's HitRecords carry: SingleMaterialHittable.Material (SingleMaterialHittable.cs:11) or the medium's private
+	/// VolumetricMaterial (ConstantDensityMedium.cs:17), which ConstantDensityMedium exposes to the backend through IDeviceMaterialOwner.</summary>
+	private static Material DeviceMaterialOf(Hittable h) => h switch
+	{
+			IDeviceMaterialOwner m => m.DeviceMaterial,
+			_                      => throw new NotSupportedException($"{h.GetType().FullName} does not expose its Material to the HIP backend")
+	};
 
 	/// <summary>RGB24 rows (row 0 = top, as Image&lt;Rgb24&gt;) into ImageBuffer; counters into RenderStats (RenderStats.cs:12-93).</summary>
 	private static void Publish(RenderJob job, IntPtr hRender)
@@ -258,44 +350,24 @@ internal sealed unsafe class HipRenderBackend
 		RenderStats rs = job.RenderStats;
 		rs.PixelsRendered = s.PixelsRendered; rs.PassesRendered = s.PassesRendered; rs.MaterialScatterCount = s.MaterialScatterCount;
 		rs.MaterialAbsorbedCount = s.MaterialAbsorbedCount; rs.SkyRays = s.SkyRays; rs.BounceLimitExceeded = s.BounceLimitExceeded; rs.RayCount = s.RayCount;
+		rs.AabbMisses = s.AabbMisses; rs.HittableMisses = s.HittableMisses; rs.HittableIntersections = s.HittableIntersections;   // RenderStats.cs: the three BVH counters the GUI panels show
 		for (int d = 0; d < 64; d++) if (s.RayDepthCounts[d] != 0) rs.RayDepthCounts[d] = s.RayDepthCounts[d];
 	}
 
 	private static RtHip.Camera FlattenCamera(Camera c)
 	{
 		RtHip.Camera r = new() { LensRadius = c.LensRadius };
-		Put(r.LookFrom, c.LookFrom); Put(r.Horizontal, c.Horizontal); Put(r.Vertical, c.Vertical); Put(r.LowerLeftCorner, c.LowerLeftCorner); Put(r.U, c.U); Put(r.V, c.V);
+		RtHip.Put(r.LookFrom, c.LookFrom); RtHip.Put(r.Horizontal, c.Horizontal); RtHip.Put(r.Vertical, c.Vertical); RtHip.Put(r.LowerLeftCorner, c.LowerLeftCorner);
+		RtHip.Put(r.U, c.U); RtHip.Put(r.V, c.V);
 		return r;
 	}
 
 	private static RtHip.SkyBox FlattenSky(SkyBox sky)
 	{
-		// DefaultSkyBox -> type 0, SingleColourSkyBox -> type 1 + colour; both implement IDeviceFlattenable in Impl and fill a RtHip.SkyBox
 		if (sky is not IDeviceSkyBox s) throw new NotSupportedException($"{sky.GetType().FullName}: user-defined SkyBoxes are rejected by the HIP backend");
 		return s.FlattenSkyBox();
 	}
-
-	[MethodImpl(MethodImplOptions.AggressiveInlining)]
-	private static void Put(float* dst, System.Numerics.Vector3 v) { dst[0] = v.X; dst[1] = v.Y; dst[2] = v.Z; }
 }
 
-/// <summary>Implemented by DefaultSkyBox and SingleColourSkyBox.</summary>
-public interface IDeviceSkyBox { internal RtHip.SkyBox FlattenSkyBox(); }
-
-// Example of the per-type flatteners added to Ararem.RayTracer.Impl (one per builtin class; Sphere.cs:17-22 shown):
-//
-//   public sealed partial class Sphere : IDeviceFlattenable
-//   {
-//       uint IDeviceFlattenable.Flatten(DeviceSceneBuilder b)
-//       {
-//           RtHip.Sphere s = new() { Radius = Radius }; s.Centre[0] = Centre.X; s.Centre[1] = Centre.Y; s.Centre[2] = Centre.Z;
-//           b.Spheres.Add(s);
-//           uint index = (uint)b.Spheres.Count - 1;
-//           b.AddObject(0 /* RT_HIT_SPHERE */, index, Material, BoundingVolume);
-//           return index;
-//       }
-//   }
-//
-// SimpleLightBase.DistanceAttenuationFunc is a delegate (SimpleLightBase.cs:132-139): the factories at :83-129 are changed to
-// return a small record { Kind, P0, P1, P2, Func } so the flattener reads Kind/P* instead of probing the lambda; a light built
-// with a hand-written lambda has Kind = Custom and is rejected.
+/// <summary>Implemented by SingleMaterialHittable (returns Material) and ConstantDensityMedium (returns its internal VolumetricMaterial).</summary>
+public interface IDeviceMaterialOwner { Material DeviceMaterial { get; } }

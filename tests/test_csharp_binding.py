@@ -1,0 +1,205 @@
+"""The C# side of the boundary (csharp/*.cs) against include/rt_hip.h, without a .NET toolchain: every [StructLayout(Sequential)]
+struct is compared with the C struct it mirrors field by field (order, scalar type, array length), every [DllImport] with the
+declared entry points (name, return type, parameter count and kinds), the constants with the header's enums and macros, and the
+Impl flatteners with the list of builtin classes in the reference tree's Impl directories that SURVEY §8a puts on the path."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+BACKEND = open(os.path.join(ROOT, "csharp", "HipRenderBackend.cs")).read()
+FLATTENERS = open(os.path.join(ROOT, "csharp", "Impl", "DeviceFlatteners.cs")).read()
+
+
+def strip_c_comments(t):
+    return re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", t, flags=re.S))
+
+
+C_SCALARS = {"uint32_t": "u32", "int32_t": "i32", "float": "f32", "uint64_t": "u64", "double": "f64", "char": "u8", "uint8_t": "u8", "int": "i32"}
+CS_SCALARS = {"uint": "u32", "int": "i32", "float": "f32", "ulong": "u64", "double": "f64", "byte": "u8"}
+# C struct -> C# struct
+STRUCTS = {"rt_sphere": "Sphere", "rt_quad": "Quad", "rt_triangle": "Triangle", "rt_infinite_plane": "InfinitePlane", "rt_axis_plane": "AxisPlane",
+           "rt_disk": "Disk", "rt_box": "Box", "rt_capsule": "Capsule", "rt_cylinder": "Cylinder", "rt_medium": "Medium", "rt_object": "Object",
+           "rt_texture": "Texture", "rt_material": "Material", "rt_light": "Light", "rt_skybox": "SkyBox", "rt_camera": "Camera",
+           "rt_scene_desc": "SceneDesc", "rt_scene_info": "SceneInfo", "rt_render_opts": "RenderOpts", "rt_stats": "Stats", "rt_ray": "Ray", "rt_hit": "Hit",
+           "rt_kernel_profile": "KernelProfile"}
+
+
+def macros():
+    out = {}
+    for m in re.finditer(r"#define\s+(RT_[A-Z0-9_]+)\s+\(?([0-9xA-Fa-fuU<\s]+?)\)?\s*(?:/\*|$)", HEADER, flags=re.M):
+        try:
+            out[m.group(1)] = int(eval(re.sub(r"[uU]\b", "", m.group(2))))
+        except Exception:
+            pass
+    for m in re.finditer(r"\b(RT_[A-Z0-9_]+)\s*=\s*(\d+)", strip_c_comments(HEADER)):      # enumerators used as array sizes (RT_K_COUNT)
+        out.setdefault(m.group(1), int(m.group(2)))
+    return out
+
+
+def c_structs():
+    text, mac, out = strip_c_comments(HEADER), macros(), {}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\}\s*\1;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            ptr = "*" in decl
+            decl = decl.replace("const ", "").replace("*", " ")
+            typ, rest = decl.split(None, 1)
+            for name in rest.split(","):
+                name = name.strip()
+                arr = re.match(r"(\w+)\[(\w+)\]", name)
+                n = 1
+                if arr:
+                    name, n = arr.group(1), (int(arr.group(2)) if arr.group(2).isdigit() else mac[arr.group(2)])
+                kind = "ptr" if ptr else C_SCALARS.get(typ, "struct:" + STRUCTS.get(typ, typ))
+                fields.append((name.replace("_", "").lower(), kind, n))
+        out[m.group(1)] = fields
+    return out
+
+
+def cs_structs():
+    out = {}
+    for m in re.finditer(r"\[StructLayout\(LayoutKind\.Sequential\)\]\s*public (?:unsafe )?struct (\w+)\s*\{(.*?)\}", strip_c_comments(BACKEND), flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            assert decl.startswith("public "), decl
+            decl = decl[len("public "):]
+            fixed = decl.startswith("fixed ")
+            if fixed:
+                decl = decl[len("fixed "):]
+            typ, rest = decl.split(None, 1)
+            assert "," not in rest, f"one field per declaration keeps the layout readable: {decl}"
+            name, n = rest.strip(), 1
+            if fixed:
+                a = re.match(r"(\w+)\[(\d+)\]", name)
+                name, n = a.group(1), int(a.group(2))
+            kind = "ptr" if (typ.endswith("*") or typ == "IntPtr") else CS_SCALARS.get(typ, "struct:" + typ)
+            fields.append((name.lower(), kind, n))
+        out[m.group(1)] = fields
+    return out
+
+
+@pytest.mark.parametrize("c_name", sorted(STRUCTS))
+def test_struct_layout_matches_the_header(c_name):
+    c, cs = c_structs()[c_name], cs_structs()[STRUCTS[c_name]]
+    assert [f[1:] for f in c] == [f[1:] for f in cs], f"{c_name}: kinds / array lengths differ\n C : {c}\n C#: {cs}"
+    assert [f[0] for f in c] == [f[0] for f in cs], f"{c_name}: field names differ\n C : {[f[0] for f in c]}\n C#: {[f[0] for f in cs]}"
+
+
+def test_every_header_struct_has_a_csharp_twin():
+    assert set(c_structs()) == set(STRUCTS)
+
+
+def c_functions():
+    out = {}
+    text = strip_c_comments(HEADER)
+    for m in re.finditer(r"^(const char\*|int)\s+(rt_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+        params = [] if m.group(3).strip() in ("", "void") else [p.strip() for p in m.group(3).split(",")]
+        kinds = ["ptr" if "*" in p else C_SCALARS[p.replace("const ", "").split()[0]] for p in params]
+        out[m.group(2)] = ("ptr" if "*" in m.group(1) else "i32", kinds)
+    return out
+
+
+def cs_functions():
+    out = {}
+    for m in re.finditer(r"\[DllImport\(Lib\)\]\s*public static extern (\w+)\s+(rt_\w+)\(([^)]*)\)\s*;", BACKEND):
+        params = [p.strip() for p in m.group(3).split(",")] if m.group(3).strip() else []
+        kinds = []
+        for p in params:
+            typ = p.split()[-2] if not p.startswith("out ") else "out"
+            kinds.append("ptr" if (typ == "out" or typ.endswith("*") or typ == "IntPtr") else CS_SCALARS[typ])
+        out[m.group(2)] = ("ptr" if m.group(1) == "IntPtr" else CS_SCALARS[m.group(1)], kinds)
+    return out
+
+
+def test_dllimports_are_exactly_the_declared_entry_points():
+    c, cs = c_functions(), cs_functions()
+    assert sorted(c) == sorted(cs), f"missing in C#: {sorted(set(c) - set(cs))}; not in the header: {sorted(set(cs) - set(c))}"
+    for name in c:
+        assert c[name] == cs[name], f"{name}: C {c[name]} vs C# {cs[name]}"
+
+
+def test_constants_match_the_header():
+    mac = macros()
+    def cs_const(name):
+        m = re.search(r"\b" + name + r"\s*=\s*([0-9xA-Fa-fuU<\s]+?)\s*[,;]", BACKEND)
+        assert m, name
+        return int(eval(re.sub(r"[uU]\b", "", m.group(1))))
+    assert cs_const("AbiVersion") == mac["RT_ABI_VERSION"] and cs_const("MaxDevices") == mac["RT_MAX_DEVICES"]
+    assert cs_const("NoHit") == mac["RT_NO_HIT"] and cs_const("RenderExactLightSampling") == mac["RT_RENDER_EXACT_LIGHT_SAMPLING"]
+    assert cs_const("TraceNoAllocMaxRays") == mac["RT_TRACE_NOALLOC_MAX_RAYS"]
+    assert cs_const("MatFlagAlternateRefraction") == mac["RT_MAT_FLAG_ALTERNATE_REFRACTION"] and cs_const("MatFlagDirectEmission") == mac["RT_MAT_FLAG_DIRECT_EMISSION"]
+    enums = {}
+    for m in re.finditer(r"\b(RT_(?:HIT|TEX|MAT|LIGHT|ATTEN|SKY)_[A-Z_]+)\s*=\s*(\d+)", strip_c_comments(HEADER)):
+        enums[m.group(1)] = int(m.group(2))
+    for c_name, value in enums.items():
+        if c_name.endswith("_COUNT") or "FLAG" in c_name:
+            continue
+        cs_name = "".join(p.capitalize() for p in c_name[3:].lower().split("_"))       # RT_HIT_XY_PLANE -> HitXyPlane
+        assert cs_const(cs_name) == value, c_name
+    # the attenuation record's kinds (csharp/Impl/DistanceAttenuation.cs) are rt_attenuation_kind's
+    rec = open(os.path.join(ROOT, "csharp", "Impl", "DistanceAttenuation.cs")).read()
+    kinds = {"Constant": "RT_ATTEN_CONSTANT", "Linear": "RT_ATTEN_LINEAR", "Logistic": "RT_ATTEN_LOGISTIC", "LogisticLkx": "RT_ATTEN_LOGISTIC_LKX", "ExponentialDecay": "RT_ATTEN_EXP_DECAY"}
+    for fn, c_name in kinds.items():
+        m = re.search(r"public static DistanceAttenuation " + fn + r"\([^)]*\)\s*=>\s*new\((\d+),", rec)
+        assert m and int(m.group(1)) == enums[c_name], fn
+    assert re.search(r"new DistanceAttenuation\(3, power", rec) and re.search(r"new DistanceAttenuation\(2, power", rec)      # POWER_STAY_HIGH = 3, POWER = 2
+    assert enums["RT_ATTEN_POWER"] == 2 and enums["RT_ATTEN_POWER_STAY_HIGH"] == 3
+
+
+# the builtin classes SURVEY §8a rows a10-a23 put on the path, by namespace, and the record each one's flattener fills
+FLATTENED = {
+    "Hittables": {"Sphere": "Spheres", "Quad": "Quads", "Triangle": "Triangles", "InfinitePlane": "InfinitePlanes", "XYPlane": "XyPlanes", "XZPlane": "XzPlanes",
+                  "YZPlane": "YzPlanes", "Disk": "Disks", "Box": "Boxes", "Capsule": "Capsules", "Cylinder": "Cylinders", "ConstantDensityMedium": "Media",
+                  "VolumetricMaterial": "Materials"},
+    "Textures": {"SolidColourTexture": "Textures", "MarbleTexture": "Textures", "GreyscaleNoiseTexture": "Textures"},
+    "Materials": {"StandardMaterial": "Materials", "RefractiveMaterial": "Materials", "EmissiveRefractiveMaterial": "Materials", "PhongMaterial": "Materials"},
+    "Lights": {"PointLight": "Lights", "DiffuseSphereLight": "Lights", "DiffuseShapedLight": "Lights"},
+}
+
+
+def test_every_builtin_class_has_a_flattener_that_fills_its_table():
+    for ns, classes in FLATTENED.items():
+        block = FLATTENERS[FLATTENERS.index(f"namespace Ararem.RayTracer.Impl.{ns}"):]
+        for cls, table in classes.items():
+            m = re.search(r"partial class " + cls + r"\b.*?\n\t\}\n", block, flags=re.S)
+            assert m, f"{ns}.{cls} has no partial class"
+            assert f"b.{table}.Add(" in m.group(0), f"{ns}.{cls} does not append to {table}"
+    for sky in ("DefaultSkyBox", "SingleColourSkyBox"):
+        assert re.search(r"partial class " + sky + r" : IDeviceSkyBox", FLATTENERS)
+    # what must NOT be flattenable: opaque user code
+    assert "partial class CustomFunctionTexture" not in FLATTENERS
+
+
+def test_flatteners_cover_the_reference_tree_when_it_is_mounted():
+    """In the build container the reference is mounted: every class file in Impl/{Hittables,Materials,Lights,Skyboxes} and the
+    flattenable textures must have a partial class here (the test skips on the GPU box, where /root/reference does not exist)."""
+    ref = "/root/reference/Ararem.RayTracer.Impl"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not mounted")
+    rejected = {"CustomFunctionTexture", "SingleMaterialHittable", "SimpleLightBase"}      # opaque delegate / abstract bases (handled as partial bases)
+    for sub in ("Hittables", "Materials", "Lights", "Skyboxes", "Textures"):
+        for f in sorted(os.listdir(os.path.join(ref, sub))):
+            cls = f[:-3]
+            if not f.endswith(".cs") or cls in rejected:
+                continue
+            assert re.search(r"partial class " + cls + r"\b", FLATTENERS), f"Impl/{sub}/{f} has no flattener"
+    for base in ("SingleMaterialHittable", "SimpleLightBase"):
+        assert re.search(r"abstract (?:unsafe )?partial class " + base + r"\b", FLATTENERS)
+
+
+def test_backend_publishes_every_reference_stat_and_orders_destruction():
+    for field in ("PixelsRendered", "PassesRendered", "MaterialScatterCount", "MaterialAbsorbedCount", "SkyRays", "BounceLimitExceeded", "RayCount", "AabbMisses",
+                  "HittableMisses", "HittableIntersections"):
+        assert re.search(r"rs\." + field + r"\s*=\s*s\." + field, BACKEND), field
+    assert BACKEND.index("rt_render_destroy(hRender)") < BACKEND.index("rt_scene_destroy(hScene)")
+    assert "interface IRenderBackend" in BACKEND and "class HipRenderBackend : IRenderBackend" in BACKEND
+    assert "MaxPassesPerCall = PassesPerCall" in BACKEND
