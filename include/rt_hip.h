@@ -16,7 +16,7 @@
  *     (row-vector convention: v' = v * M, element Mrc = row r, column c).
  *   - an object's id is its index in rt_scene_desc.objects (== index in Scene.SceneObjects);
  *     a material's id is its index in rt_scene_desc.materials (one entry per distinct Material
- *     *reference*: RefractiveMaterial.cs:41-42 and EmissiveRefractiveMaterial.cs:27-33 compare
+ *     *reference*: RefractiveMaterial.cs:51-52 and EmissiveRefractiveMaterial.cs:53-63 compare
  *     materials by identity).
  *   - user-defined Hittable/Material/Texture/Light/SkyBox subclasses have no table here: the
  *     flattener must reject them (no CPU fallback exists in this library).
@@ -180,30 +180,30 @@ typedef struct rt_material {
 } rt_material;
 
 typedef enum rt_light_type {
-    RT_LIGHT_POINT          = 0,     /* PointLight.cs:7 */
-    RT_LIGHT_DIFFUSE_SPHERE = 1,     /* DiffuseSphereLight.cs:85-139 (the hard-wired `case 4`) */
-    RT_LIGHT_DIFFUSE_SHAPED = 2      /* DiffuseShapedLight.cs:67-103 */
+    RT_LIGHT_POINT          = 0,     /* PointLight.cs:9 */
+    RT_LIGHT_DIFFUSE_SPHERE = 1,     /* DiffuseSphereLight.cs:88-142 (the hard-wired `case 4`) */
+    RT_LIGHT_DIFFUSE_SHAPED = 2      /* DiffuseShapedLight.cs:69-105 */
 } rt_light_type;
 
-/* SimpleLightBase.DistanceAttenuationFunc is a delegate (SimpleLightBase.cs:55-79); the flattener
+/* SimpleLightBase.DistanceAttenuationFunc is a delegate (SimpleLightBase.cs:132-139; factories :83-129); the flattener
  * classifies it into one of the factory families below or rejects the light. x = kMax / AttenuationRadius. */
 typedef enum rt_attenuation_kind {
     RT_ATTEN_CONSTANT        = 0,    /* p[0]                        (e.g. BuiltinScenes.cs:146 `(_, _) => 1f`) */
-    RT_ATTEN_LINEAR          = 1,    /* 1 - x                        SimpleLightBase.cs:56 */
-    RT_ATTEN_POWER           = 2,    /* Pow(1 - x, p[0])             :63 */
-    RT_ATTEN_POWER_STAY_HIGH = 3,    /* 1 - Pow(x, p[0])             :65 */
-    RT_ATTEN_LOGISTIC        = 4,    /* 1 / (1 + Pow(E, p[1] * (x - p[0])))   midpoint p[0], steepness p[1]  :70 */
-    RT_ATTEN_LOGISTIC_LKX    = 5,    /* p[0] / (1 + Pow(E, -p[1] * (x - p[2])))                              :73 */
-    RT_ATTEN_EXP_DECAY       = 6     /* Pow(E, p[0] * -x)            :75 (default, p[0]=5, :77) */
+    RT_ATTEN_LINEAR          = 1,    /* 1 - x                        SimpleLightBase.cs:83 */
+    RT_ATTEN_POWER           = 2,    /* Pow(1 - x, p[0])             :95-103 */
+    RT_ATTEN_POWER_STAY_HIGH = 3,    /* 1 - Pow(x, p[0])             :95-103 (stayHighInitially) */
+    RT_ATTEN_LOGISTIC        = 4,    /* 1 / (1 + Pow(E, p[1] * (x - p[0])))   midpoint p[0], steepness p[1]  :115 */
+    RT_ATTEN_LOGISTIC_LKX    = 5,    /* p[0] / (1 + Pow(E, -p[1] * (x - p[2])))                              :125 */
+    RT_ATTEN_EXP_DECAY       = 6     /* Pow(E, p[0] * -x)            :129 (default, p[0]=5, :132) */
 } rt_attenuation_kind;
 
 typedef struct rt_light {
     uint32_t type;
     float    position[3];
     float    colour[3];
-    float    attenuation_radius;     /* SimpleLightBase.cs:15 */
-    float    cutoff_radius;          /* :17 */
-    float    diffusion_radius;       /* DiffuseSphereLight.cs:11 */
+    float    attenuation_radius;     /* SimpleLightBase.cs:27 */
+    float    cutoff_radius;          /* :34 */
+    float    diffusion_radius;       /* DiffuseSphereLight.cs:13 */
     uint32_t atten_kind;
     float    atten_p[3];
     uint32_t shape_type;             /* DIFFUSE_SHAPED: rt_hittable_type of Shape ... */
@@ -378,12 +378,12 @@ int rt_scene_get_info(rt_scene* scene, rt_scene_info* out);
 int rt_render_create(rt_scene* scene, const rt_render_opts* opts, rt_render** out);
 int rt_render_destroy(rt_render* render);
 
-/* RenderInternal's pass loop body (RenderJob.cs:92-122) for passes first_pass, first_pass+pass_stride, ...
+/* The pass loop body of RenderInternal (RenderJob.cs:69-126), :92-122, for passes first_pass, first_pass+pass_stride, ...
  * (n_passes of them). pass_stride > 1 is how a caller shards passes over devices (pass p goes to
  * device p mod G). Blocking. */
 int rt_render_passes(rt_render* render, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride);
 
-/* UpdateBuffers' resolve (RenderJob.cs:646-654): avg -> Clamp01 -> Sqrt -> (byte)(255*c); row 0 = top.
+/* The resolve at the end of UpdateBuffers (RenderJob.cs:626-655), :646-654: avg -> Clamp01 -> Sqrt -> (byte)(255*c); row 0 = top.
  * Before the first pass the image is black, as the reference's freshly constructed Image<Rgb24> is. */
 int rt_render_read_rgb24(rt_render* render, uint8_t* dst /* width*height*3 */);
 /* rawColourBuffer / sampleCountBuffer (RenderJob.cs:669-672), image-row order (row 0 = top). */

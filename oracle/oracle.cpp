@@ -915,13 +915,13 @@ static Colour SkyColour(const SceneData& sc, const Ray& ray) {
 // Lights: Impl/Lights/SimpleLightBase.cs, PointLight.cs, DiffuseSphereLight.cs, DiffuseShapedLight.cs
 // ---------------------------------------------------------------------------------------------
 struct ShadowRay { Ray ray; float kMin, kMax; };
-static ShadowRay DefaultGetShadowRayForHit(V3 hitPos, V3 lightPos) {                                   // SimpleLightBase.cs:42-51
+static ShadowRay DefaultGetShadowRayForHit(V3 hitPos, V3 lightPos) {                                   // SimpleLightBase.cs:68-77
     Ray r = Ray::FromPoints(hitPos, lightPos);
     const float kMin = 0.01f;
     float kMax = Distance(hitPos, lightPos) - kMin;
     return {r, kMin, kMax};
 }
-static float Attenuation(const rt_light& l, float x) {                                                 // SimpleLightBase.cs:55-77
+static float Attenuation(const rt_light& l, float x) {                                                 // the factories, SimpleLightBase.cs:83-129
     switch (l.atten_kind) {
         case RT_ATTEN_CONSTANT: return l.atten_p[0];
         case RT_ATTEN_LINEAR: return 1 - x;
@@ -935,8 +935,8 @@ static float Attenuation(const rt_light& l, float x) {                          
 static ShadowRay GetShadowRayForHit(const SceneData& sc, uint32_t li, const HitRecord& hit, const SampleKey& key, uint32_t slotBase, uint32_t sub) {
     const rt_light& l = sc.lights[li];
     V3 Position = v3(l.position);
-    if (l.type == RT_LIGHT_POINT) return DefaultGetShadowRayForHit(hit.WorldPoint, Position);          // PointLight.cs:7
-    if (l.type == RT_LIGHT_DIFFUSE_SPHERE) {                                                           // DiffuseSphereLight.cs:85-139
+    if (l.type == RT_LIGHT_POINT) return DefaultGetShadowRayForHit(hit.WorldPoint, Position);          // PointLight.cs:9
+    if (l.type == RT_LIGHT_DIFFUSE_SPHERE) {                                                           // DiffuseSphereLight.cs:88-142
         float DiffusionRadius = l.diffusion_radius;
         if (Distance(hit.WorldPoint, Position) <= DiffusionRadius * 1.01f) {
             for (int i = 0; i < 1000; i++) {
@@ -962,7 +962,7 @@ static ShadowRay GetShadowRayForHit(const SceneData& sc, uint32_t li, const HitR
         V3 randPos = Position + (randDir * DiffusionRadius);
         return DefaultGetShadowRayForHit(hit.WorldPoint, randPos);
     }
-    // DiffuseShapedLight.cs:67-103
+    // DiffuseShapedLight.cs:69-105
     const Hittable* shape = sc.lightShapes[li].get();
     V3 mn = v3(l.shape_aabb_min), mx = v3(l.shape_aabb_max);
     for (int i = 0; i < 1000; i++) {
@@ -975,7 +975,7 @@ static ShadowRay GetShadowRayForHit(const SceneData& sc, uint32_t li, const HitR
     }
     return {Ray(hit.WorldPoint, v3(1.0f)), 0.0f, INF};
 }
-// SimpleLightBase.CalculateLight, :22-40
+// SimpleLightBase.CalculateLight, SimpleLightBase.cs:48-66
 static Colour CalculateLight(const SceneData& sc, uint32_t li, const HitRecord& hit, const SampleKey& key, uint32_t sub, Stats& st, Ray* outRay = nullptr, bool raw = false) {
     const rt_light& l = sc.lights[li];
     ShadowRay s = GetShadowRayForHit(sc, li, hit, key, raw ? SLOT_LIGHT_RAW : SLOT_LIGHT, sub);
@@ -1008,20 +1008,20 @@ static Ray Scatter(const RenderCtx& rc, const HitRecord& hit, const HitRecord* p
     const rt_material& m = rc.sc->materials[hit.Material];
     SampleKey::F4 r = key.draw(SLOT_SCATTER, 0);
     switch (m.type) {
-        case RT_MAT_STANDARD: {                                                                        // StandardMaterial.cs:45-52
+        case RT_MAT_STANDARD: {                                                                        // StandardMaterial.cs:64-72
             V3 diffuse = OnUnitSphere(r.x, r.y, r.z);
             if (Dot(diffuse, hit.Normal) < 0) diffuse = diffuse * -1.0f;
             V3 reflect = Reflect(hit.IncomingRay.d, hit.Normal);
             return Ray(hit.WorldPoint, Normalize(Lerp(reflect, diffuse, m.f[0])));
         }
-        case RT_MAT_PHONG: {                                                                           // PhongMaterial.cs:18-28
+        case RT_MAT_PHONG: {                                                                           // PhongMaterial.cs:26-37
             V3 dir = OnUnitSphere(r.x, r.y, r.z);
             if (Dot(dir, hit.Normal) < 0) dir = dir * -1.0f;
             return Ray(hit.WorldPoint, dir);
         }
         case RT_MAT_VOLUMETRIC:                                                                        // ConstantDensityMedium.cs:102
             return Ray(hit.WorldPoint, OnUnitSphere(r.x, r.y, r.z));
-        default: {                                                                                     // RefractiveMaterial.cs:27-88
+        default: {                                                                                     // RefractiveMaterial.cs:37-99
             V3 unitDirection = Normalize(hit.IncomingRay.d);
             float cosTheta = MinF(Dot(-unitDirection, hit.Normal), 1.0f);
             float sinTheta = std::sqrt(1.0f - (cosTheta * cosTheta));
@@ -1056,15 +1056,15 @@ static Colour CalculateColour(const RenderCtx& rc, Colour future, const HitRecor
     const SceneData& sc = *rc.sc;
     const rt_material& m = sc.materials[hit.Material];
     switch (m.type) {
-        case RT_MAT_STANDARD: {                                                                        // StandardMaterial.cs:54-60
+        case RT_MAT_STANDARD: {                                                                        // StandardMaterial.cs:74-80
             Colour colour = CalculateSimpleColourFromLights(rc, hit, key, st) + future;
             colour = colour * TextureColour(sc, m.tex[0], hit);
             colour = colour + TextureColour(sc, m.tex[1], hit);
             return colour;
         }
-        case RT_MAT_REFRACTIVE:                                                                        // RefractiveMaterial.cs:90-92
+        case RT_MAT_REFRACTIVE:                                                                        // RefractiveMaterial.cs:101-103
             return (future + CalculateSimpleColourFromLights(rc, hit, key, st)) * TextureColour(sc, m.tex[0], hit);
-        case RT_MAT_EMISSIVE_REFRACTIVE: {                                                             // EmissiveRefractiveMaterial.cs:17-38
+        case RT_MAT_EMISSIVE_REFRACTIVE: {                                                             // EmissiveRefractiveMaterial.cs:43-64
             Colour colour = future;
             colour = colour + CalculateSimpleColourFromLights(rc, hit, key, st);
             colour = colour * TextureColour(sc, m.tex[0], hit);
@@ -1073,7 +1073,7 @@ static Colour CalculateColour(const RenderCtx& rc, Colour future, const HitRecor
             if (prevCount == 1 && prev[0].Material == hit.Material) return colour;
             return colour + TextureColour(sc, m.tex[1], hit);
         }
-        case RT_MAT_PHONG: {                                                                           // PhongMaterial.cs:30-76
+        case RT_MAT_PHONG: {                                                                           // PhongMaterial.cs:39-85
             Colour Specular = col(m.f), Diffuse = col(m.f + 3), Ambient = col(m.f + 6);
             float Shininess = m.f[9];
             Colour rawDiffuse = Black, rawSpecular = Black;
@@ -1099,7 +1099,7 @@ static Colour CalculateColour(const RenderCtx& rc, Colour future, const HitRecor
             }
             return Ambient + (rawDiffuse * Diffuse) + (rawSpecular * Specular);
         }
-        default: {                                                                                     // VolumetricMaterial, ConstantDensityMedium.cs:105-129
+        default: {                                                                                     // the private VolumetricMaterial.CalculateColour, ConstantDensityMedium.cs:105-129 (class at :87)
             float pw = m.f[3] * hit.ShaderData;
             return Colour{std::pow(m.f[0], pw), std::pow(m.f[1], pw), std::pow(m.f[2], pw)} * future;
         }
@@ -1369,7 +1369,7 @@ int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, ui
     return RT_OK;
 }
 
-// UpdateBuffers' resolve, Core/RenderJob.cs:646-654 ; Colour.Clamp01/Sqrt/(Rgb24), Core/Colour.cs:197-234
+// the resolve at the end of UpdateBuffers (Core/RenderJob.cs:626-655), :646-654 ; Colour.Clamp01/Sqrt/(Rgb24), Core/Colour.cs:197-234
 int orc_resolve_rgb24(const float* rgb_sum, uint32_t sample_count, uint32_t width, uint32_t height, uint8_t* dst) {
     uint64_t n = (uint64_t)width * height * 3;
     for (uint64_t i = 0; i < n; i++) {

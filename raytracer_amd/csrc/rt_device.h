@@ -885,7 +885,7 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
             else nrm = mk3(r1.z, r1.w, r2.x) * bs.s.z;
             h.n = normalize(nrm);
             h.outside = dot(r.d, nrm) < 0.0f;
-            if (WANT_UV) {                                                                // Transform(worldPoint, WorldToBoxTransform), Box.cs:181
+            if (WANT_UV) {                                                                // LocalPoint = Transform(worldPoint, WorldToBoxTransform), Box.cs:172
                 float4 m0 = b[0], m1 = b[1], m2 = b[2];
                 h.lp = mk3((h.wp.x * m0.x) + (h.wp.y * m0.w) + (h.wp.z * m1.z) + m2.y, (h.wp.x * m0.y) + (h.wp.y * m1.x) + (h.wp.z * m1.w) + m2.z,
                            (h.wp.x * m0.z) + (h.wp.y * m1.y) + (h.wp.z * m2.x) + m2.w);
@@ -1031,7 +1031,7 @@ template <bool EXACT>
 RT_FN ShadowRay default_shadow_ray(f3 hitPos, f3 lightPos) {                             // SimpleLightBase.DefaultGetShadowRayForHit, SimpleLightBase.cs:68-77
     ShadowRay s; s.r.o = hitPos; s.kMin = 0.01f;
     if constexpr (EXACT) {
-        s.r.d = normalize(lightPos - hitPos);                                            // Ray.FromPoints -> the Ray ctor normalises (Core/Ray.cs:17,26)
+        s.r.d = normalize(lightPos - hitPos);                                            // Ray.FromPoints (Core/Ray.cs:26) -> the Ray ctor normalises (:17)
         s.kMax = distance(hitPos, lightPos) - 0.01f;                                     // Vector3.Distance(hitPos, lightPos) - kMin
     } else {
         f3 v = lightPos - hitPos;
@@ -1053,7 +1053,7 @@ RT_FN float attenuation(const rt_light* l, float x) {                           
         default: return exp_e<EXACT>(l->atten_p[0] * -x);
     }
 }
-// SimpleLightBase.CalculateLight after the occlusion test, SimpleLightBase.cs:57-65: cutoff, attenuation of kMax / AttenuationRadius, clamp at 0
+// what SimpleLightBase.CalculateLight (SimpleLightBase.cs:48-66) does after the occlusion test, :57-65: cutoff, attenuation of kMax / AttenuationRadius, clamp at 0
 template <bool EXACT>
 RT_FN col3 light_contribution(const rt_light* l, float kMax) {
     if (kMax > l->cutoff_radius) return mkc(0, 0, 0);

@@ -7,7 +7,7 @@
 //   k_closest : position j -> closest hit (BVH traversal, per-lane stack in LDS)            RenderJob.cs:581-617
 //   k_shade   : hit/miss -> sky, scatter, affine colour terms, shadow requests; survivors
 //               and shadow requests get their output positions from one block scan          RenderJob.cs:413-451, materials
-//   k_shadow  : one thread per shaded hit, LightSampleCountHint x |lights| any-hit rays      Material.cs:30-45, SimpleLightBase.cs:22-40
+//   k_shadow  : one thread per shaded hit, LightSampleCountHint x |lights| any-hit rays      Material.cs:30-45, SimpleLightBase.cs:48-66
 // A path that ends writes its radiance to out[path id]; k_accumulate adds those into the image sums in pass order
 // (RenderJob.cs:626-647) and k_resolve makes RGB24 (RenderJob.cs:646-654).
 //
@@ -284,7 +284,7 @@ RT_FN col3 bounce_depth_colour(int maxDepthReached, uint32_t maxAllowedDepth) {
     return (mkc(1, 1, 1) * (1.0f - val)) + ((mkc(0, 0, 1) * 0.02f) * val);
 }
 
-// `sum / samples` of Material.CalculateSimpleColourFromLights (Material.cs:43): Colour / float divides every channel
+// `sum /= samples` at the end of Material.CalculateSimpleColourFromLights (Material.cs:30-45), :42: Colour / float divides every channel
 template <bool EXACT> RT_FN col3 over_samples(col3 sum, float S) { if constexpr (EXACT) return sum / S; else return sum * rcp_fast(S); }
 
 // VIS = RenderOptions.DebugVisualisation != None (RenderJob.cs:148-309): the same kernel decides a debug colour from the first hit
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 col3 a = mkc(1, 1, 1);        // multiplier of the future colour
                 col3 W = mkc(0, 0, 0);        // weight of the light sum
                 switch (m->type) {
-                    case RT_MAT_STANDARD: if constexpr (RT_HAS_MAT(C, RT_MAT_STANDARD)) {                                            // StandardMaterial.cs:45-60
+                    case RT_MAT_STANDARD: if constexpr (RT_HAS_MAT(C, RT_MAT_STANDARD)) {                                            // StandardMaterial.cs:64-80 (Scatter :64-72, CalculateColour :74-80)
                         f3 diffuse = on_unit_sphere(u.x, u.y, u.z);
                         if (dot(diffuse, h.n) < 0) diffuse = diffuse * -1.0f;
                         f3 refl = reflect(r.d, h.n);
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                         L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
                         W = T * a;
                     } break;
-                    case RT_MAT_PHONG: if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                                               // PhongMaterial.cs:18-76
+                    case RT_MAT_PHONG: if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                                               // PhongMaterial.cs:26-85 (Scatter :26-37, CalculateColour :39-85)
                         f3 dir = on_unit_sphere(u.x, u.y, u.z);
                         if (dot(dir, h.n) < 0) dir = dir * -1.0f;
                         nr.d = normalize(dir);
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                         float pw = m->f[3] * h.shader;
                         a = mkc(powf(m->f[0], pw), powf(m->f[1], pw), powf(m->f[2], pw));
                     } break;
-                    default: if constexpr (RT_HAS_MAT(C, RT_MAT_REFRACTIVE) || RT_HAS_MAT(C, RT_MAT_EMISSIVE_REFRACTIVE)) {            // RefractiveMaterial.cs:27-92, EmissiveRefractiveMaterial.cs:17-38
+                    default: if constexpr (RT_HAS_MAT(C, RT_MAT_REFRACTIVE) || RT_HAS_MAT(C, RT_MAT_EMISSIVE_REFRACTIVE)) {            // RefractiveMaterial.cs:37-103, EmissiveRefractiveMaterial.cs:43-64
                         f3 ud = normalize(r.d);
                         float cosT = minf_net(dot(-ud, h.n), 1.0f);
                         float sinT = sqrtf(1.0f - (cosT * cosT));
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS && !EXACT 
                 col3 c = mkc(0, 0, 0);
                 if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
                 if (!phong) sum = sum + c;
-                else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:42-56
+                else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:50-65
                     ShadowRay s2 = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
                     col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                     if (!occluded) c = light_contribution<EXACT>(l, kMax);
                     if (!phong) sum = sum + c;
                     else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) { cdd = c * fabsf(dot(r.d, nrm)); second = true; advance = false; }
-                } else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {              // PhongMaterial.cs:42-56
+                } else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {              // PhongMaterial.cs:50-65
                     col3 c2 = occluded ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
                     f3 rl = reflect(r.d, -nrm);
                     float sd = fabsf(dot(in, rl));

@@ -930,7 +930,7 @@ int rt_render_resolve_device(rt_render* r, const float* accum_device, uint32_t s
 
 int rt_render_read_rgb24(rt_render* r, uint8_t* dst) {
     if (!r || !dst) return fail(RT_ERR_INVALID_ARG, "rt_render_read_rgb24: null argument");
-    // before the first pass the reference's Image<Rgb24> is what its constructor left: black (UpdateBuffers has not run, RenderJob.cs:40-47)
+    // before the first pass the reference's Image<Rgb24> is what the RenderJob constructor left (RenderJob.cs:40-47): black — no sample has been resolved into it yet
     if (r->sample_count == 0) { memset(dst, 0, (size_t)r->rd.n_pixels * 3); return RT_OK; }
     if (r->shards.empty()) return rt_render_resolve_device(r, r->accum, r->sample_count, dst);
     DeviceGuard guard(r->device);

@@ -86,7 +86,7 @@ def _as_texture(x) -> Texture:
 
 
 class StandardMaterial(Material):
-    """StandardMaterial.cs:16-52.  StandardMaterial(albedo, diffusion) or StandardMaterial(albedo, emission, diffusion);
+    """StandardMaterial.cs:16-61.  StandardMaterial(albedo, diffusion) or StandardMaterial(albedo, emission, diffusion);
     albedo/emission may be Colours or Textures."""
 
     def __init__(self, albedo, emission_or_diffusion, diffusion=None):
@@ -101,7 +101,7 @@ class StandardMaterial(Material):
 
 
 class RefractiveMaterial(Material):
-    """RefractiveMaterial.cs:13-25"""
+    """RefractiveMaterial.cs:20-34"""
     AirIndex, GlassIndex, DiamondIndex = 1.0, 1.5, 2.4
 
     def __init__(self, refractiveIndex, tint, alternateRefractionMode=False):
@@ -115,7 +115,7 @@ class RefractiveMaterial(Material):
 
 
 class EmissiveRefractiveMaterial(RefractiveMaterial):
-    """EmissiveRefractiveMaterial.cs:30-34"""
+    """EmissiveRefractiveMaterial.cs:30-40"""
 
     def __init__(self, refractiveIndex, tint, emission, directEmission=False, alternateRefractionMode=False):
         super().__init__(refractiveIndex, tint, alternateRefractionMode)
@@ -127,7 +127,7 @@ class EmissiveRefractiveMaterial(RefractiveMaterial):
 
 
 class PhongMaterial(Material):
-    """PhongMaterial.cs:10-23 (init-only properties with defaults)"""
+    """PhongMaterial.cs:11-23 (init-only properties with defaults)"""
 
     def __init__(self, SpecularColour=None, DiffuseColour=None, AmbientColour=None, Shininess=0.0):
         self.SpecularColour = Colour.White if SpecularColour is None else SpecularColour
@@ -483,7 +483,7 @@ class PointLight(SimpleLightBase):
 
 
 class DiffuseSphereLight(SimpleLightBase):
-    """DiffuseSphereLight.cs:9-12"""
+    """DiffuseSphereLight.cs:10-13"""
     _type = capi.LIGHT_DIFFUSE_SPHERE
 
     def __init__(self, DiffusionRadius=0.0, **kw):
