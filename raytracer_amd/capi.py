@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  
 RT_ABI_VERSION = 2
 RT_MAX_DEVICES = 16
 RENDER_EXACT_LIGHT_SAMPLING = 1
+RENDER_EXACT_OCCLUSION = 2
 RT_NO_HIT = 0xFFFFFFFF
 RT_DEPTH_HIST_SIZE = 64
 

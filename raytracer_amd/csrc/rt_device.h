@@ -118,7 +118,10 @@ struct SceneDev {
     const rt_material* materials;
     const rt_texture* textures;
     const rt_light* lights;      uint32_t n_lights;
-    float bounds_centre[3], bounds_radius, max_object_radius;    // sphere around every bounded object; largest half-diagonal of one object's box (any_pad)
+    float bounds_centre[3], bounds_radius, max_object_radius;    // sphere around every bounded object; largest half-diagonal of one object's box (any_box)
+    float min_round_radius;                                      // smallest radius of a sphere / capsule / cylinder in the tree or list, FLT_MAX without any (any_box)
+    float any_again;                                             // a second look is due when the sphere term of the pad exceeds this many smallest radii (RT_HIP_ANY_AGAIN)
+    float any_pad_scale;                                         // 1; RT_HIP_ANY_PAD_SCALE overrides (A/B knob: 0 = boxes as they are, the culling of round 1)
     rt_camera camera;
     rt_skybox skybox;
     // small all-sphere scenes: a copy of the tree laid out for LDS (see LdsTree), null otherwise
@@ -444,22 +447,27 @@ RT_FN TravCount trav_count_zero() { TravCount c; c.nodes = 0; c.prims = 0; c.box
 
 // Any-hit traversal culls by boxes, the reference's AnyIntersectionFast does not (BinaryBvhNode.cs:41 asks every object).  The
 // answers agree as long as no intersector accepts a point outside its object's box — true in exact arithmetic, not in binary32: a
-// sphere test at distance D from the ray origin carries an error of up to ~1e-6 D^2 in its discriminant (cancellation in
-// halfB^2 - a c), so a ray that passes the sphere at up to sqrt(r^2 + 1e-6 D^2) can be reported as a hit, 1e-3 D outside the box
-// (observed: shadow rays from ground points 2 000 units away in the Demo scene).  So any-hit tests every box grown by
-// pad = 1.1e-3 * D + 1e-5 (the sphere's worst case is sqrt(18 * 2^-24) D = 1.04e-3 D), D = the farthest the centre of an object
-// the ray can report may be: the ray's range, capped by the far side of the scene, plus twice the largest object's half-diagonal.  Growing a box by pad on every side = measuring its min planes from origin + pad and its max
-// planes from origin - pad, so the node test costs no extra instruction (AnyBox below).
+// sphere test at distance D from the ray origin carries an error of up to 18 * 2^-24 * D^2 = 1.07e-6 D^2 in its discriminant
+// (cancellation in halfB^2 - a c), so a ray that passes a sphere of radius r at up to sqrt(r^2 + 1.07e-6 D^2) can be reported as a
+// hit (observed: shadow rays from ground points 2 000 units away in the Demo scene, 1 unit outside the box).  So the any-hit box
+// test sees every box larger by
+//   pad = sqrt(rmin^2 + 1.1e-6 reach^2) - rmin   the sphere bound at the ray's reach (rmin = the smallest sphere / capsule /
+//         cylinder radius of the scene; a larger radius errs less); nothing in scenes of planar primitives only, whose error is
+//         linear and whose reference boxes are padded by 1e-4 already (Quad.cs:43, XYPlane.cs:27)
+//       + 1e-6 reach + 1e-5 + 2.4e-7 |origin|     the rounding of the reported root and of the FMA plane form
+//   reach = the ray's range, capped by the far side of the scene, plus the largest object's half-diagonal.
+// The ray's range needs no widening: the point o + t d of a reported root t lies within `pad` of its object, hence inside the
+// padded box at that very t, so the box's interval and [kMin, kMax] share t.
+// Night Spheres: pad = 1.5e-3 on spheres of 0.1 and up (nothing).  100 k spheres of 0.05 .. 0.25, lights up to 100 units away:
+// 0.07 at full reach — see the two looks of any_box.
+//
 // A ray prepared for node box tests.  ClosestBox is the reference's arithmetic (AxisAlignedBoundingBox.Hit, operand for operand: a
-// leaf's box test decides whether its object is asked at all, so its bits matter).  AnyBox is the any-hit form: the boxes grown by
-// `pad`, and — no reference arithmetic to reproduce here, BinaryBvhNode.FastTryHit has no box test — one fused multiply-add per
-// plane, t = plane * inv + (-(origin -+ pad) * inv): 6 packed FMAs per node instead of 6 packed subtracts and 6 packed multiplies.
-// The FMA form places a plane with an absolute error of ~2^-23 |origin| (the rounding of the precomputed addend), which the
-// pad absorbs (any_box adds it); 1/d is clamped to +-1e30 so that an axis-parallel ray gives +-huge, not inf - inf = NaN.
+// leaf's box test decides whether its object is asked at all, so its bits matter).  AnyBox is the any-hit form: padded boxes, and —
+// no reference arithmetic to reproduce here, BinaryBvhNode.FastTryHit has no box test — one fused multiply-add per plane,
+// t = plane * inv + addend: 6 packed FMAs per node instead of 6 packed subtracts and 6 packed multiplies.  The FMA form places a
+// plane with an absolute error of ~2^-23 |origin| (the rounding of the precomputed addend), which pad0 absorbs; reciprocals are
+// v_rcp_f32 (1 ulp is plenty here) clamped to +-1e30, so an axis-parallel ray gives +-huge, not inf - inf = NaN.
 // o8x/y/z: 8 where the ray runs against the axis, else 0 — the byte offset that makes LdsTree's node layout hand out near/far planes.
-#ifndef RT_ANY_FMA
-#define RT_ANY_FMA 1
-#endif
 struct ClosestBox {
     f3 o, inv; uint32_t o8x, o8y, o8z;
     RT_FN void fold(const NodePlanes& p, float kMin, float& enA, float& exA, float& enB, float& exB) const {
@@ -473,19 +481,16 @@ RT_FN ClosestBox closest_box(const Ray& r) {
     return b;
 }
 struct AnyBox {
-    f3 inv, an, af; uint32_t o8x, o8y, o8z;      // an / af belong to the near / far plane of each axis: RT_ANY_FMA the addends, otherwise the shifted origins
+    f3 inv, an, af;                   // per axis: t_near = near plane * inv + an, t_far = far plane * inv + af
+    uint32_t o8x, o8y, o8z;
     RT_FN void fold(const NodePlanes& p, float kMin, float& enA, float& exA, float& enB, float& exB) const {
         const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
         const v2f anx = {an.x, an.x}, any = {an.y, an.y}, anz = {an.z, an.z}, afx = {af.x, af.x}, afy = {af.y, af.y}, afz = {af.z, af.z};
-#if RT_ANY_FMA
         fold_planes(__builtin_elementwise_fma(p.nx, ix, anx), __builtin_elementwise_fma(p.fx, ix, afx), __builtin_elementwise_fma(p.ny, iy, any),
                     __builtin_elementwise_fma(p.fy, iy, afy), __builtin_elementwise_fma(p.nz, iz, anz), __builtin_elementwise_fma(p.fz, iz, afz), kMin, enA, exA, enB, exB);
-#else
-        fold_planes((p.nx - anx) * ix, (p.fx - afx) * ix, (p.ny - any) * iy, (p.fy - afy) * iy, (p.nz - anz) * iz, (p.fz - afz) * iz, kMin, enA, exA, enB, exB);
-#endif
     }
 };
-RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax);
+RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax, float cap, int mode, bool& again);
 
 RT_FN void consider(Closest& best, float k, uint32_t obj, float aux) {
     if (best.obj != RT_NO_HIT && k == best.k && best.obj > obj) return;
@@ -511,7 +516,7 @@ RT_FN bool ray_has_nan(Ray r) { return is_nan(r.o.x) || is_nan(r.o.y) || is_nan(
 // the 64-B node record (q0 q1 q2 of struct Node) -> near / far planes for this ray
 template <class Box>
 RT_FN void planes_of(float4 q0, float4 q1, float4 q2, const Box& box, NodePlanes& p) {
-    const bool gx = box.inv.x < 0.0f, gy = box.inv.y < 0.0f, gz = box.inv.z < 0.0f;
+    const bool gx = box.o8x != 0u, gy = box.o8y != 0u, gz = box.o8z != 0u;
     const v2f mnx = {q0.x, q0.y}, mny = {q0.z, q0.w}, mnz = {q1.x, q1.y}, mxx = {q1.z, q1.w}, mxy = {q2.x, q2.y}, mxz = {q2.z, q2.w};
     p.nx = gx ? mxx : mnx; p.fx = gx ? mnx : mxx;
     p.ny = gy ? mxy : mny; p.fy = gy ? mny : mxy;
@@ -524,7 +529,9 @@ struct HbmTree {
     int* stack; int stride;
     template <class Box> RT_FN void planes(const SceneDev& sc, int i, const Box& box, NodePlanes& p, int2& ch) const {
         const Node* np = sc.nodes + i;
-        planes_of(np->q0, np->q1, np->q2, box, p); ch = *(const int2*)&np->q3;
+        const float4 q0 = np->q0, q1 = np->q1, q2 = np->q2; ch = *(const int2*)&np->q3;
+        __builtin_amdgcn_sched_barrier(0);       // all four loads in flight before the first wait (left alone the scheduler issues the children's load after waiting for the planes: two memory round trips per node, 100 k spheres k_shadow 656 vs 518 ms)
+        planes_of(q0, q1, q2, box, p);
     }
     RT_FN void push(int sp, int v) const { stack[sp * stride] = v; }
     RT_FN int pop(int sp) const { return stack[sp * stride]; }
@@ -701,33 +708,51 @@ RT_FN bool list_any(const SceneDev& sc, const Ray& r, const AnyBox& box, float k
 }
 
 RT_FN float rcp_fast(float a);
-RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax) {
-    const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
-    const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;      // no bounded object is farther from the origin
-    const float reach = (kMax < far_side ? kMax : far_side) + (2.0f * sc.max_object_radius);     // (a NaN kMax leaves far_side)
-    float pad = (1.1e-3f * reach) + 1e-5f;
+// the box test of a ray that sees every box larger by `pad` on every side
+RT_FN AnyBox make_any_box(const Ray& r, float pad) {
     AnyBox b;
-#if RT_ANY_FMA
-    f3 inv = mk3(rcp_fast(r.d.x), rcp_fast(r.d.y), rcp_fast(r.d.z));      // 1 ulp is plenty for boxes grown by pad (a correctly rounded divide is 11 instructions)
-#else
-    f3 inv = splat(1.0f) / r.d;
-#endif
-#if RT_ANY_FMA
-    pad = pad + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)));
-    inv = mk3(__builtin_fminf(__builtin_fmaxf(inv.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(inv.y, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(inv.z, -1e30f), 1e30f));
-#endif
-    b.inv = inv;
-    const bool gx = inv.x < 0.0f, gy = inv.y < 0.0f, gz = inv.z < 0.0f;
-    b.o8x = gx ? 8u : 0u; b.o8y = gy ? 8u : 0u; b.o8z = gz ? 8u : 0u;
-    // the box grown by pad: its min planes move by -pad, its max planes by +pad; the near plane is the min plane unless the ray runs against the axis
-    const f3 on = mk3(gx ? r.o.x - pad : r.o.x + pad, gy ? r.o.y - pad : r.o.y + pad, gz ? r.o.z - pad : r.o.z + pad);
-    const f3 of = mk3(gx ? r.o.x + pad : r.o.x - pad, gy ? r.o.y + pad : r.o.y - pad, gz ? r.o.z + pad : r.o.z - pad);
-#if RT_ANY_FMA
-    b.an = -on * inv; b.af = -of * inv;
-#else
-    b.an = on; b.af = of;
-#endif
+    const float dd[3] = {r.d.x, r.d.y, r.d.z}, oo[3] = {r.o.x, r.o.y, r.o.z};
+    float in_[3], an_[3], af_[3]; uint32_t o8[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const bool neg = __builtin_signbitf(dd[i]);
+        const float sp = neg ? -pad : pad;
+        in_[i] = __builtin_fminf(__builtin_fmaxf(rcp_fast(dd[i]), -1e30f), 1e30f);
+        an_[i] = -(oo[i] + sp) * in_[i];                                                        // near plane: the min plane moved by -pad for a ray along +axis, the max plane moved by +pad otherwise
+        af_[i] = -(oo[i] - sp) * in_[i];
+        o8[i] = neg ? 8u : 0u;
+    }
+    b.inv = mk3(in_[0], in_[1], in_[2]); b.an = mk3(an_[0], an_[1], an_[2]); b.af = mk3(af_[0], af_[1], af_[2]);
+    b.o8x = o8[0]; b.o8y = o8[1]; b.o8z = o8[2];
     return b;
+}
+// Two looks.  Padded boxes only ever ADD candidates, and a hit found in the boxes as they are is a hit of the reference's scan too
+// (the same FastTryHit said yes).  So when the pad is large against the objects (a ray reaching 100 units through 0.05-unit
+// spheres; a shadow ray from a ground point 10 000 units out, whose sphere tests are noise the size of the whole scene) the ray is
+// first traced through the boxes as they are — in a dense scene it is occluded within a few units and done — and only a ray that
+// comes out unoccluded is traced again through the padded boxes, where the object that answers yes from outside its box is found.
+// When the pad is small (<= 0.1 rmin) the padded boxes are the only look.
+//   cap: the sphere term of the pad is limited to cap * rmin.  Infinite under RT_RENDER_EXACT_OCCLUSION and in rt_trace_any: every
+//        answer is the reference scan's, at the price of horizon rays that ask every object of the scene (as the reference does
+//        for every ray).  0.5 otherwise: exact up to reach = 1 100 rmin by the worst-case bound, ~2 500 rmin by the error observed;
+//        beyond that a noise hit of the reference outside 1.5 radii is missed (pixels at the horizon of an infinite ground plane —
+//        the 100 k-sphere scene renders 20x faster for it).
+//   mode: 0 = first look (sets `again` when a second one is due), 1 = the second look.
+RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax, float cap, int mode, bool& again) {
+    const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
+    const float len = __builtin_amdgcn_sqrtf(dot(r.d, r.d));                                     // 1 for every ray the renderer makes; callers of rt_trace_any may pass any length
+    const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;      // no bounded object is farther from the origin
+    const float range = kMax * len;
+    const float reach = (range < far_side ? range : far_side) + sc.max_object_radius;            // world units (a NaN kMax leaves far_side): no centre of a reported hit is farther
+    float round = 0.0f, rm = 3e38f;
+    if (sc.min_round_radius < 3e38f) {
+        rm = sc.min_round_radius;
+        round = __builtin_fminf((__builtin_amdgcn_sqrtf((rm * rm) + (1.1e-6f * reach * reach)) - rm) * 1.02f, cap * rm);
+    }
+    again = mode == 0 && round > (sc.any_again * rm);
+    if (again) return make_any_box(r, 0.0f);
+    // + the rounding of the reported root (1e-6 reach), the reference's own margins, and the plane error of the FMA form
+    return make_any_box(r, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))));
 }
 
 template <class C, class Tree>
@@ -771,7 +796,7 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
 // RenderJob.AnyIntersectionFast, Core/RenderJob.cs:575.  The reference scans every object's FastTryHit; culling by
 // conservative boxes returns the same boolean.
 template <class C, class Tree>
-RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, TravCount& cnt) {
+RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, float cap, TravCount& cnt) {
     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
         uint32_t code = sc.obj_code[sc.unbounded[i]]; cnt.prims++;
         if (fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax)) return true;
@@ -783,21 +808,27 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
         }
     }
     if (!(Tree::list && sc.n_list_pairs) && !sc.n_nodes) return false;
-    const AnyBox box = any_box(sc, r, kMax);
-    if (Tree::list && sc.n_list_pairs) return list_any<C>(sc, r, box, kMin, kMax, cnt);
-    int sp = 0, cur = 0, pend = TRAV_DONE;
-    uint32_t unused = 0;
-    for (;;) {
-        if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); } }
-        else while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
-        if (pend != TRAV_DONE) {
-            cnt.prims++;
-            if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) return true;
+    bool again;
+    AnyBox box = any_box(sc, r, kMax, cap, 0, again);
+    for (;;) {                                                   // once, or twice (see any_box)
+        if (Tree::list && sc.n_list_pairs) { if (list_any<C>(sc, r, box, kMin, kMax, cnt)) return true; }
+        else {
+            int sp = 0, cur = 0, pend = TRAV_DONE;
+            uint32_t unused = 0;
+            for (;;) {
+                if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); } }
+                else while (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
+                if (pend != TRAV_DONE) {
+                    cnt.prims++;
+                    if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) return true;
+                }
+                if (cur == TRAV_DONE) break;
+                leaf_advance(tree, cur, pend, sp);
+            }
         }
-        if (cur == TRAV_DONE) break;
-        leaf_advance(tree, cur, pend, sp);
+        if (!again) return false;
+        box = any_box(sc, r, kMax, cap, 1, again);
     }
-    return false;
 }
 
 // ------------------------------------------------------------------------------------------------

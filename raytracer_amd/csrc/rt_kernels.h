@@ -48,6 +48,7 @@ struct RenderDev {
     uint64_t seed;
     float k_min, k_max;
     uint32_t max_depth, light_samples;
+    float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
 
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
 
 #endif
 
+#define RT_ANY_GROWTH_CAP 0.5f         // any_box without RT_RENDER_EXACT_OCCLUSION
 extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsTree: scene image, then ushort [stack_depth][block]
 
 // Traversal kernels come in two forms: TB = BLOCK reading the tree through the cache hierarchy, and (small all-sphere scenes)
@@ -473,10 +475,13 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
 // waves per SIMD the LDS-tree shadow kernel is held to.  6 (80 VGPRs) spills 15 registers around the traversal, 7 more: measured on
 // Night Spheres 1080p per 256-pass step 5 waves 74.5 ms, 6 waves 80.7 ms, 7 waves 87.2 ms (profiles/r02_d_ab.log)
 #ifndef RT_SHADOW_LDS_WAVES
-#define RT_SHADOW_LDS_WAVES 5
+#define RT_SHADOW_LDS_WAVES 4
 #endif
+// waves per SIMD k_shadow is held to when the tree is read from HBM, per variant (none specialised: holding the Cornell variant to
+// 4 waves = 128 VGPRs instead of its 157 spills 22 of them and is slower, 56.9 vs 53.5 ms per batch)
+template <class C> struct ShadowTune { static constexpr int min_waves = 1; };
 template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS && !EXACT ? RT_SHADOW_LDS_WAVES : 1) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LDS ? RT_SHADOW_LDS_WAVES : ShadowTune<C>::min_waves) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
@@ -505,12 +510,12 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, LDS && !EXACT 
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
                 rays++;
                 col3 c = mkc(0, 0, 0);
-                if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
+                if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
                 if (!phong) sum = sum + c;
                 else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:50-65
                     ShadowRay s2 = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
-                    col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
+                    col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, rd.any_cap, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
                     f3 rl = reflect(s2.r.d, -nrm);
                     float sd = fabsf(dot(in, rl));
                     spec_sum = spec_sum + (c2 * powf(sd, powf(2.0f, m->f[9])));
@@ -564,7 +569,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     const rt_material* m = nullptr; bool phong = false;
     col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0);
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-    AnyBox box; box.inv = mk3(0, 0, 0); box.an = r.o; box.af = r.o; box.o8x = 0; box.o8y = 0; box.o8z = 0;
+    bool again = false;                  // the ray in flight gets a second look through grown boxes if it comes out unoccluded (any_box)
+    AnyBox box = make_any_box(r, 0.0f);
     uint32_t unused = 0;
     float kMin = 0, kMax = 0;
     int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
@@ -572,7 +578,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     for (;;) {
         bool fetched = false;
         if (cur == TRAV_DONE && pend == TRAV_DONE) {
-            if (flying) {                                                       // ---- account for the finished ray
+            if (flying && again && !occluded) {                                 // ---- unoccluded in the boxes as they are: look again in the grown ones
+                box = any_box(sc, r, kMax, rd.any_cap, 1, again);
+                cur = 0; sp = 0;
+            } else if (flying) {                                                // ---- account for the finished ray
                 flying = false;
                 const rt_light* l = sc.lights + li;
                 bool advance = true;
@@ -620,7 +629,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                 sum = mkc(0, 0, 0); spec_sum = mkc(0, 0, 0);
                 q = 0; li = 0; second = false; have = true;
             }
-            if (have) {                                                         // ---- next ray of the request
+            if (have && !flying) {                                              // ---- next ray of the request
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
                 r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
                 rays++; flying = true; occluded = false;
@@ -634,7 +643,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                         occluded = fast_object_solid<C>(sc, md.boundary_type, md.boundary_index, r, kMin, kMax);      // ConstantDensityMedium.cs:77
                     }
                 }
-                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax); cur = 0; sp = 0; }
+                again = false;
+                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = 0; }
             }
         }
         next += (uint32_t)__popcll(__ballot(fetched));
@@ -723,7 +733,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(Sc
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         TravCount cnt = trav_count_zero();
-        occluded[i] = any_hit<C>(sc, tree, r, kMin[i], kMax[i], cnt) ? 1 : 0;
+        occluded[i] = any_hit<C>(sc, tree, r, kMin[i], kMax[i], __builtin_inff(), cnt) ? 1 : 0;
     }
 }
 

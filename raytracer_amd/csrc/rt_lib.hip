@@ -2,6 +2,7 @@
 // BVH build, wavefront scheduling of the kernels in rt_kernels.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -137,6 +138,7 @@ struct rt_render {
     rt_render_opts opts{};
     RenderDev rd{};                  // slot 0's view (shared fields)
     bool exact_lights = false;       // RT_RENDER_EXACT_LIGHT_SAMPLING / RT_HIP_EXACT_LIGHTS=1
+    bool exact_occlusion = false;    // RT_RENDER_EXACT_OCCLUSION / RT_HIP_EXACT_OCCLUSION=1
     uint32_t passes_per_batch = 1;
     size_t max_paths = 0;
     hipStream_t stream = nullptr; bool own_stream = false;     // the stream results are ordered on (slot 0's)
@@ -449,6 +451,18 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         double r2 = 0.0;
         for (int a = 0; a < 3; a++) { const double c = boxes.empty() ? 0.0 : 0.5 * (lo[a] + hi[a]), e = boxes.empty() ? 0.0 : 0.5 * (hi[a] - lo[a]); sd.bounds_centre[a] = (float)c; r2 += e * e; }
         sd.bounds_radius = (float)(std::sqrt(r2) * 1.0001 + 1e-6); sd.max_object_radius = (float)(max_half * 1.0001);
+        // the smallest sphere / capsule / cylinder among the bounded objects (media boundaries and light shapes are not in the tree)
+        float rmin = FLT_MAX;
+        for (uint32_t obj : box_obj) {
+            const rt_object& o = d->objects[obj];
+            if (o.type == RT_HIT_SPHERE) rmin = std::min(rmin, std::fabs(d->spheres[o.index].radius));
+            else if (o.type == RT_HIT_CAPSULE) rmin = std::min(rmin, std::fabs(d->capsules[o.index].radius));
+            else if (o.type == RT_HIT_CYLINDER) rmin = std::min(rmin, std::fabs(d->cylinders[o.index].radius));
+        }
+        sd.min_round_radius = rmin;
+        sd.any_pad_scale = 1.0f; sd.any_again = RT_ANY_GROWTH_CAP;
+        if (const char* e = getenv("RT_HIP_ANY_AGAIN")) sd.any_again = (float)atof(e);
+        if (const char* e = getenv("RT_HIP_ANY_PAD_SCALE")) sd.any_pad_scale = (float)atof(e);
     }
     s->stack_depth = std::max<uint32_t>(bvh.max_depth + 1, 2); s->bvh_depth = bvh.max_depth;
     if ((size_t)s->stack_depth * BLOCK * sizeof(int) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "BVH depth %u needs more LDS than one workgroup may use", bvh.max_depth);
@@ -657,7 +671,7 @@ static int check_render_opts(const rt_render_opts* o) {
         return fail(RT_ERR_INVALID_ARG, "Wrong enum value for debug visualisation (%u)", o->debug_visualisation);                           // RenderJob.cs:307-308
     if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
     if ((uint64_t)o->width * o->height > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
-    if (o->flags & ~RT_RENDER_EXACT_LIGHT_SAMPLING) return fail(RT_ERR_INVALID_ARG, "unknown bits in rt_render_opts.flags (0x%x)", o->flags);
+    if (o->flags & ~(RT_RENDER_EXACT_LIGHT_SAMPLING | RT_RENDER_EXACT_OCCLUSION)) return fail(RT_ERR_INVALID_ARG, "unknown bits in rt_render_opts.flags (0x%x)", o->flags);
     if (o->n_devices > RT_MAX_DEVICES) return fail(RT_ERR_TOO_LARGE, "n_devices %u above RT_MAX_DEVICES (%d)", o->n_devices, RT_MAX_DEVICES);
     return RT_OK;
 }
@@ -673,6 +687,7 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
     r->scene = s; r->device = s->device; r->opts = *o;
     s->live_renders.fetch_add(1);
     { const char* e = getenv("RT_HIP_EXACT_LIGHTS"); r->exact_lights = (o->flags & RT_RENDER_EXACT_LIGHT_SAMPLING) || (e && e[0] == '1'); }
+    { const char* e = getenv("RT_HIP_EXACT_OCCLUSION"); r->exact_occlusion = (o->flags & RT_RENDER_EXACT_OCCLUSION) || (e && e[0] == '1'); }
     // paths per batch: the alive paths fall to ~1 % by bounce 10, and a launch needs >> 0.5 M rays to fill 256 CUs, so batches are
     // big (128 M paths = 26 GB of state per slot): sized for 288 GB of HBM, not for a cache — but never for more passes than the
     // caller will ask for in one call (max_passes_per_call), and never for more than the device has free right now.
@@ -748,6 +763,7 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
         rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
         rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+        rd.any_cap = r->exact_occlusion ? INFINITY : RT_ANY_GROWTH_CAP;
         rd.vis = o->debug_visualisation;
     }
     r->rd = r->slots[0].rd;

@@ -126,7 +126,7 @@ def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0, devices=Non
     ro.device = device
     ro.stream = stream or None
     ro.accum_device = accum_device or None
-    ro.flags = capi.RENDER_EXACT_LIGHT_SAMPLING if getattr(o, "ExactLightSampling", False) else 0
+    ro.flags = (capi.RENDER_EXACT_LIGHT_SAMPLING if getattr(o, "ExactLightSampling", False) else 0) | (capi.RENDER_EXACT_OCCLUSION if getattr(o, "ExactOcclusion", False) else 0)
     if devices:
         if len(devices) > capi.RT_MAX_DEVICES:
             raise ValueError(f"at most {capi.RT_MAX_DEVICES} devices")

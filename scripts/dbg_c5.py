@@ -1,34 +1,18 @@
-import numpy as np, sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+"""A/B of the any-hit knobs on the 100 k-sphere scene (GPU box): second-look threshold x persistent lanes x exact occlusion."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 from raytracer_amd import builtin_scenes as bs
-from raytracer_amd.flatten import flatten_scene
-from oracle import binding as ob
-import helpers
-sc=bs.ManySpheresManyLights(); flat=flatten_scene(sc); dev=rt.DeviceScene(flat); orc=ob.OracleScene(flat)
-print(dev.Info())
-rs=np.random.default_rng(24)
-o1,d1=helpers.camera_rays(sc,64,64,50000,rs); o2,d2=helpers.secondary_rays(flat,50000,rs)
-o=np.concatenate([o1,o2]); d=np.concatenate([d1,d2])
-g=dev.TraceClosest(o,d,0.001,np.inf,seed=7); r=orc.trace_closest(o,d,0.001,np.inf,seed=7)
-bad=np.nonzero(g["object"]!=r["object"])[0]
-import ctypes as C
-sph=np.frombuffer((C.c_char*(flat.desc.n_spheres*16)).from_address(C.addressof(flat.desc.spheres.contents)),np.float32).reshape(-1,4)
-for i in bad:
-    print(i, "o",o[i],"d",d[i])
-    print(" gpu",g["object"][i],repr(g["k"][i]),"ref",r["object"][i],repr(r["k"][i]))
-    for ob_ in (g["object"][i], r["object"][i]):
-        if ob_!=0xFFFFFFFF and ob_<len(sph): print("  sphere",ob_,sph[ob_])
-objs=np.frombuffer((C.c_char*(flat.n_objects*36)).from_address(C.addressof(flat.desc.objects.contents)),np.uint32).reshape(-1,9)
-def isect(oi, o, d):
-    t,idx=objs[oi,0],objs[oi,1]
-    c=sph[idx,:3].astype(np.float64); rad=float(sph[idx,3])
-    oc=o.astype(np.float64)-c; dd=d.astype(np.float64)
-    a=dd@dd; hb=oc@dd; cc=oc@oc-rad*rad; disc=hb*hb-a*cc
-    return t,idx,sph[idx],disc,((-hb-np.sqrt(max(disc,0)))/a,(-hb+np.sqrt(max(disc,0)))/a)
-for i in bad:
-    for ob_ in (g["object"][i], r["object"][i]):
-        print("  obj",ob_,isect(ob_,o[i],d[i]))
-    aabb=objs[:,3:].view(np.float32)
-    for ob_ in (g["object"][i], r["object"][i]):
-        print("  aabb",ob_,aabb[ob_])
+from raytracer_amd.core import RenderOptions
+sc = bs.ManySpheresManyLights()
+W, H = (int(a) for a in (sys.argv[1:3] or (1920, 1080)))
+for again, exact in (("0.1", False), ("0.25", False), ("1.0", False), ("0.1", True)):
+    for pers in ("0", "1"):
+        os.environ["RT_HIP_ANY_AGAIN"] = again; os.environ["RT_HIP_PERSISTENT_SHADOW"] = pers
+        dev = rt.DeviceScene(sc)
+        opt = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=1, MaxBounceDepth=10, LightSampleCountHint=1, PassesPerBatch=1, ExactOcclusion=exact)
+        job = rt.RenderJob(sc, opt, device_scene=dev)
+        t0 = time.perf_counter(); job.RenderPasses(0, 1, 1); dt = time.perf_counter() - t0
+        s = job.UpdateStats()
+        print(f"again {again} exact {exact} persistent {pers}: {dt*1e3:.1f} ms  shadow rays {s.ShadowRays}  boxes/ray {s.ShadowNodeVisits/max(s.ShadowRays,1):.1f}  prims/ray {s.ShadowPrimTests/max(s.ShadowRays,1):.2f}", flush=True)
+        job.Dispose(); dev.Dispose()

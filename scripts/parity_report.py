@@ -20,7 +20,7 @@ def main():
         sc = helpers.small_scenes()[name](); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
         ref = None
         for exact in (False, True):
-            opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234, ExactLightSampling=exact)
+            opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234, ExactLightSampling=exact, ExactOcclusion=exact)
             job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); st = job.RenderStats; job.Dispose()
             if ref is None:
                 ref, rst = orc.render(opt, threads=8)

@@ -1,13 +1,33 @@
 #!/usr/bin/env python3
-"""Throughput of every BASELINE.json config on one GPU (full scene size and resolution, bounded spp): one JSON line per config.
-usage: python scripts/run_configs.py [c2 c3 c4 c5]"""
+"""Throughput and roofline of every BASELINE.json config on one GPU (full scene size and resolution, bounded spp): one JSON line per
+config that a reader can recompute.
+
+    python scripts/run_configs.py [c1 c2 c3 c4 c5] [--short] [--traffic profiles/r02_traffic_configs.json]
+
+Per config: Msamples/s and Mrays/s over `passes` passes (two batch slots in flight), then ONE batch with per-kernel HIP-event timing
+(rt_render_set_profiling, kernels one at a time) from which the roofline of both traversal kernels is derived:
+
+    flops = 22 * V + F_prim * T (+ 60 * S for the shadow kernel: light sampling per shadow ray)        SURVEY §8d
+    bytes = 32 * V + B_prim * T
+    V = box tests, T = primitive tests, S = shadow rays: the device counters of that batch (rt_render_stats deltas)
+    F_prim / B_prim = the scene's census-weighted mean over its tree primitives (sphere 28/16, triangle or quad 42/48, axis plane 14/24,
+                      box 70/112, capsule 60/32, disk 42/48, cylinder 60/32), plane 12/24 for the unbounded InfinitePlane tests
+    frac_valu = flops / time / 157.3 TFLOP/s (FP32 vector peak; the kernels are built -ffp-contract=off, so half of it is their ceiling)
+    frac_hbm_model = bytes / time / 8 TB/s — the §8d byte model counts every node and primitive fetch, cached or not
+    frac_hbm_pmc   = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches / time / 8 TB/s when --traffic names a PMC file for this config
+                     (scripts/pmc_passes.sh with BENCH_CMD="python3 scripts/run_configs.py cN --short", then scripts/pmc_traffic.py)
+`roofline.frac` is frac_valu for scenes whose tree fits the caches (c1, c2, c3, c5: <= 6.4 MB of nodes) and frac_hbm_pmc (falling back
+to the model) for c4, whose 320 MB of nodes + 320 MB of triangles do not."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import raytracer_amd as rt
-from raytracer_amd import builtin_scenes as bs
+from raytracer_amd import builtin_scenes as bs, capi
 from raytracer_amd.core import RenderOptions
 
+VALU_PEAK_TFLOPS, HBM_PEAK_GBS = 157.3, 8000.0
+# (label, scene, W, H, passes, depth, light samples, passes per batch)
 CONFIGS = {
     "c1": ("Demo 480x270 depth 8", bs.Demo, 480, 270, 64, 8, 2, 64),
     "c2": ("Night Spheres 1920x1080 depth 10", bs.Testing, 1920, 1080, 128, 10, 2, 64),
@@ -15,29 +35,100 @@ CONFIGS = {
     "c4": ("Triangle mesh 4 999 122 tris 3840x2160 depth 8", bs.TriangleMesh, 3840, 2160, 32, 8, 2, 16),
     "c5": ("100 k spheres + 64 lights 3840x2160 depth 10", bs.ManySpheresManyLights, 3840, 2160, 4, 10, 1, 2),
 }
+F_PRIM = {capi.HIT_SPHERE: (28, 16), capi.HIT_QUAD: (42, 48), capi.HIT_TRIANGLE: (42, 48), capi.HIT_INFINITE_PLANE: (12, 24), capi.HIT_XY_PLANE: (14, 24),
+          capi.HIT_XZ_PLANE: (14, 24), capi.HIT_YZ_PLANE: (14, 24), capi.HIT_DISK: (42, 48), capi.HIT_BOX: (70, 112), capi.HIT_CAPSULE: (60, 32),
+          capi.HIT_CYLINDER: (60, 32), capi.HIT_MEDIUM: (56, 32)}
+F_NODE, B_NODE = 22, 32
+STAT_KEYS = ("RayCount", "ShadowRays", "NodeVisits", "PrimTests", "ShadowNodeVisits", "ShadowPrimTests", "PixelsRendered", "AabbMisses", "HittableIntersections")
+
+
+def census(flat):
+    """Object types of the scene: (count of unbounded InfinitePlanes, mean flops / bytes of a primitive test inside the tree or list)."""
+    import ctypes as C
+    n = flat.n_objects
+    raw = np.frombuffer((C.c_char * (n * 36)).from_address(C.addressof(flat.desc.objects.contents)), dtype=np.uint32).reshape(n, 9) if n else np.zeros((0, 9), np.uint32)
+    types = raw[:, 0]
+    unbounded = int((types == capi.HIT_INFINITE_PLANE).sum())
+    inside = types[types != capi.HIT_INFINITE_PLANE]
+    if len(inside) == 0:
+        return unbounded, 0.0, 0.0
+    f = np.array([F_PRIM[int(t)][0] for t in np.unique(inside)]); b = np.array([F_PRIM[int(t)][1] for t in np.unique(inside)])
+    w = np.array([(inside == t).sum() for t in np.unique(inside)], dtype=np.float64); w /= w.sum()
+    return unbounded, float((f * w).sum()), float((b * w).sum())
+
+
+def snap(job):
+    s = job.UpdateStats()
+    return {k: getattr(s, k) for k in STAT_KEYS}
+
+
+def roofline(which, d, ms, launches, n_unbounded, f_prim, b_prim):
+    rays, V, T = (d["RayCount"], d["NodeVisits"], d["PrimTests"]) if which == "closest" else (d["ShadowRays"], d["ShadowNodeVisits"], d["ShadowPrimTests"])
+    t_plane = min(rays * n_unbounded, T)                     # every ray asks every unbounded plane first (any-hit rays stop at the first hit)
+    t_tree = T - t_plane
+    flops = F_NODE * V + f_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][0] * t_plane + (60 * rays if which == "shadow" else 0)
+    byts = B_NODE * V + b_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][1] * t_plane
+    sec = ms / 1e3
+    return {"kernel": "k_" + which, "rays": rays, "box_tests_V": V, "prim_tests_T": T, "launches": launches, "total_ms": ms, "avg_launch_ms": ms / max(launches, 1),
+            "algorithmic_flops": flops, "algorithmic_bytes": byts, "tflops": flops / sec / 1e12 if sec else 0.0, "frac_valu": flops / sec / 1e12 / VALU_PEAK_TFLOPS if sec else 0.0,
+            "model_gbs": byts / sec / 1e9 if sec else 0.0, "frac_hbm_model": byts / sec / 1e9 / HBM_PEAK_GBS if sec else 0.0}
+
 
 def main():
-    which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
-    for c in which:
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    short = "--short" in sys.argv
+    traffic = {}
+    if "--traffic" in sys.argv:
+        traffic = json.load(open(sys.argv[sys.argv.index("--traffic") + 1]))
+        args = [a for a in args if not a.endswith(".json")]
+    for c in (args or list(CONFIGS)):
         label, mk, W, H, passes, depth, ls, ppb = CONFIGS[c]
+        if short:
+            passes = ppb
         sc = mk()
         t0 = time.perf_counter(); dev = rt.DeviceScene(sc); t_scene = time.perf_counter() - t0
+        n_unb, f_prim, b_prim = census(dev.flat)
         opt = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, PassesPerBatch=ppb)
         job = rt.RenderJob(sc, opt, device_scene=dev)
         job.RenderPasses(10_000, ppb, 1)                      # warm-up batch
-        s0 = job.UpdateStats(); r0, sh0, nv0, pt0, snv0, spt0 = s0.RayCount, s0.ShadowRays, s0.NodeVisits, s0.PrimTests, s0.ShadowNodeVisits, s0.ShadowPrimTests
+        s0 = snap(job)
         t0 = time.perf_counter(); job.RenderPasses(0, passes, 1); job.UpdateImage(); dt = time.perf_counter() - t0
-        s1 = job.UpdateStats()
-        rays, sh = s1.RayCount - r0, s1.ShadowRays - sh0
+        s1 = snap(job)
+        d = {k: s1[k] - s0[k] for k in s0}
+        rays, sh = d["RayCount"], d["ShadowRays"]
         out = {"config": c, "workload": label, "passes": passes, "seconds": dt, "msamples_per_s": W * H * passes / dt / 1e6,
                "mrays_per_s": {"closest": rays / dt / 1e6, "shadow": sh / dt / 1e6},
-               "box_tests_per_closest_ray": (s1.NodeVisits - nv0) / max(rays, 1), "prim_tests_per_closest_ray": (s1.PrimTests - pt0) / max(rays, 1),
-               "box_tests_per_shadow_ray": (s1.ShadowNodeVisits - snv0) / max(sh, 1), "prim_tests_per_shadow_ray": (s1.ShadowPrimTests - spt0) / max(sh, 1),
-               "scene_create_s": t_scene, "scene_info": dev.Info()}
-        job.SetProfiling(True); job.RenderPasses(20_000, ppb, 1); prof = job.KernelProfile(); job.SetProfiling(False)
+               "box_tests_per_closest_ray": d["NodeVisits"] / max(rays, 1), "prim_tests_per_closest_ray": d["PrimTests"] / max(rays, 1),
+               "box_tests_per_shadow_ray": d["ShadowNodeVisits"] / max(sh, 1), "prim_tests_per_shadow_ray": d["ShadowPrimTests"] / max(sh, 1),
+               "aabb_misses_per_closest_ray": d["AabbMisses"] / max(rays, 1), "scene_create_s": t_scene, "scene_info": dev.Info(),
+               "prim_cost_model": {"unbounded_planes": n_unb, "flops_per_tree_prim_test": f_prim, "bytes_per_tree_prim_test": b_prim}}
+        # one batch with per-kernel event timing, and the counters of exactly that batch
+        job.SetProfiling(True); p0 = snap(job); job.RenderPasses(20_000, ppb, 1); prof = job.KernelProfile(); p1 = snap(job); job.SetProfiling(False)
+        pd = {k: p1[k] - p0[k] for k in p0}
         out["kernel_ms_one_batch"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
+        rl = {w: roofline(w, pd, prof[w]["total_ms"], prof[w]["launches"], n_unb, f_prim, b_prim) for w in ("closest", "shadow")}
+        dominant = max(rl, key=lambda w: rl[w]["total_ms"])
+        r = dict(rl[dominant])
+        tr = traffic.get(c, {}).get("kernels", {})
+        tname = next((k for k in tr if k.startswith("k_" + dominant)), None)
+        hbm_bound = dev.Info()["n_nodes"] * 64 > (64 << 20)        # the tree alone exceeds the 4 MB L2s x 8 and most of the 256 MB Infinity Cache's share
+        if tname:
+            per_launch = tr[tname]["hbm_bytes_per_launch"]
+            r["traffic"] = per_launch
+            r["pmc_gbs"] = per_launch * r["launches"] / (r["total_ms"] / 1e3) / 1e9
+            r["frac_hbm_pmc"] = r["pmc_gbs"] / HBM_PEAK_GBS
+        else:
+            r["traffic"] = None
+        if hbm_bound:
+            r.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", achieved=r.get("pmc_gbs", r["model_gbs"]), frac=r.get("frac_hbm_pmc", r["frac_hbm_model"]),
+                     frac_uses="PMC FETCH_SIZE/WRITE_SIZE traffic" if tname else "the SURVEY 8d byte model (counts cached node fetches too: an upper bound on HBM traffic)")
+        else:
+            r.update(bound="valu", peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", achieved=r["tflops"], frac=r["frac_valu"], frac_uses="algorithmic flops / FP32 vector peak")
+        out["roofline"] = r
+        out["roofline_other"] = rl["shadow" if dominant == "closest" else "closest"]
         print(json.dumps(out), flush=True)
         job.Dispose(); dev.Dispose()
+
 
 if __name__ == "__main__":
     main()

@@ -110,7 +110,7 @@ def test_config2_night_spheres_1080p():
     got, st = _properties(sc, dev, opt)
     ref, rst = orc.render(opt, threads=16)
     assert _image_close(got, ref) > 0.99
-    opt_x = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=10, LightSampleCountHint=2, Seed=0xC2, ExactLightSampling=True)
+    opt_x = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=2, MaxBounceDepth=10, LightSampleCountHint=2, Seed=0xC2, ExactLightSampling=True, ExactOcclusion=True)
     job = rt.RenderJob(sc, opt_x, device_scene=dev); job.Wait(); gx, _ = job.ReadAccum(); job.Dispose()
     assert _image_close(gx, ref) >= 0.999                                         # 2 M pixels, every shadow ray identical to the oracle's
     assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] and abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"]
@@ -167,7 +167,7 @@ def test_config4_five_million_triangles(monkeypatch):
     # with culled shadow rays the oracle affords a real picture of the mesh: 480 x 270, depth 8, both shadow kernels
     dev.Dispose()
     _render_vs_culled_oracle(sc, flat, orc, RenderOptions(RenderWidth=480, RenderHeight=270, Passes=2, MaxBounceDepth=8, LightSampleCountHint=2, Seed=0xC4,
-                                                          ExactLightSampling=True), 0.999, monkeypatch)
+                                                          ExactLightSampling=True, ExactOcclusion=True), 0.999, monkeypatch)
 
 
 def test_config5_hundred_thousand_spheres_64_lights(monkeypatch):
@@ -189,7 +189,7 @@ def test_config5_hundred_thousand_spheres_64_lights(monkeypatch):
     # with culled shadow rays: 320 x 180 at the configured depth (64 shadow rays per hit: 30 M of them), both shadow kernels
     dev.Dispose()
     _render_vs_culled_oracle(sc, flat, orc, RenderOptions(RenderWidth=320, RenderHeight=180, Passes=2, MaxBounceDepth=10, LightSampleCountHint=1, Seed=0xC5,
-                                                          ExactLightSampling=True), 0.999, monkeypatch)
+                                                          ExactLightSampling=True, ExactOcclusion=True), 0.999, monkeypatch)
 
 
 def test_check1_two_million_rays_night_spheres():

@@ -106,7 +106,7 @@ def test_image_parity(pairs, name, w, h, passes, depth, ls, exact):
     other way, which changes a pixel by one light sample; >= 99 % of the pixels within 1e-3, and no pixel off by more than the light
     all its samples can receive (every light, every sample, every pass: passes x sum of the lights' brightest channel)."""
     sc, flat, dev, orc = pairs(name)
-    opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234, ExactLightSampling=exact)
+    opt = RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, Seed=1234, ExactLightSampling=exact, ExactOcclusion=exact)
     job = rt.RenderJob(sc, opt, device_scene=dev)
     job.Wait()
     got, n = job.ReadAccum()
