@@ -9,7 +9,7 @@
 //     if (RenderOptions.Backend == RenderBackend.Hip) { new HipRenderBackend().Render(this, cancellationToken); return; }
 //
 // and RenderOptions three new init-only properties: `Backend` (default Cpu, or env RT_BACKEND=hip), `Devices`
-// (HIP ordinals; default: one GPU) and `ExactLightSampling`.  Nothing else in the public surface changes: Image,
+// (HIP ordinals; default: one GPU), `ExactLightSampling` and `ExactOcclusion`.  Nothing else in the public surface changes: Image,
 // ImageBuffer, RenderStats, RenderTask, StartOrGetRenderAsync keep their meaning.
 //
 // Core cannot name Impl types (Impl -> Core, Ararem.RayTracer.Impl.csproj:23), so flattening is an interface the
@@ -59,6 +59,7 @@ public static unsafe class RtHip
 	public const uint NoHit      = 0xFFFFFFFFu;  // RT_NO_HIT
 	public const int  MaxDevices = 16;           // RT_MAX_DEVICES
 	public const uint RenderExactLightSampling = 1u;   // RT_RENDER_EXACT_LIGHT_SAMPLING
+	public const uint RenderExactOcclusion = 2u;       // RT_RENDER_EXACT_OCCLUSION
 	public const uint TraceNoAllocMaxRays = 1u << 17;  // RT_TRACE_NOALLOC_MAX_RAYS
 
 	// rt_hittable_type
@@ -298,7 +299,7 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 					StructSize = (uint)sizeof(RtHip.RenderOpts), Width = (uint)o.RenderWidth, Height = (uint)o.RenderHeight, KMin = o.KMin, KMax = o.KMax,
 					MaxBounceDepth = (uint)o.MaxBounceDepth, LightSampleCountHint = (uint)o.LightSampleCountHint, DebugVisualisation = (uint)o.DebugVisualisation,   // rt_debug_vis has the enum's values
 					Seed = (ulong)Random.Shared.NextInt64(), PassesPerBatch = 0, Device = -1, Stream = IntPtr.Zero, AccumDevice = null,
-					Flags = o.ExactLightSampling ? RtHip.RenderExactLightSampling : 0u,
+					Flags = (o.ExactLightSampling ? RtHip.RenderExactLightSampling : 0u) | (o.ExactOcclusion ? RtHip.RenderExactOcclusion : 0u),
 					MaxPassesPerCall = PassesPerCall * (uint)devices.Length,        // one call's passes are split over the devices
 					NDevices = devices.Length > 1 ? (uint)devices.Length : 0u
 			};

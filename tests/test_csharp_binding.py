@@ -135,6 +135,7 @@ def test_constants_match_the_header():
         return int(eval(re.sub(r"[uU]\b", "", m.group(1))))
     assert cs_const("AbiVersion") == mac["RT_ABI_VERSION"] and cs_const("MaxDevices") == mac["RT_MAX_DEVICES"]
     assert cs_const("NoHit") == mac["RT_NO_HIT"] and cs_const("RenderExactLightSampling") == mac["RT_RENDER_EXACT_LIGHT_SAMPLING"]
+    assert cs_const("RenderExactOcclusion") == mac["RT_RENDER_EXACT_OCCLUSION"]
     assert cs_const("TraceNoAllocMaxRays") == mac["RT_TRACE_NOALLOC_MAX_RAYS"]
     assert cs_const("MatFlagAlternateRefraction") == mac["RT_MAT_FLAG_ALTERNATE_REFRACTION"] and cs_const("MatFlagDirectEmission") == mac["RT_MAT_FLAG_DIRECT_EMISSION"]
     enums = {}
