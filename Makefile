@@ -12,11 +12,12 @@ CSRC := raytracer_amd/csrc
 LIB  := raytracer_amd/librt_hip.so
 ORC  := oracle/liboracle.so
 BENCH := tools/rtbench
+CALIB := tools/calib_fetch
 
-all: $(LIB) $(ORC) $(BENCH)
+all: $(LIB) $(ORC) $(BENCH) $(CALIB)
 
 HDRS := $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_bvh.h include/rt_hip.h
-OBJS := $(addprefix build/,rt_lib.o rt_lbvh.o rt_bvh.o rt_variant_spheres.o rt_variant_mesh.o rt_variant_boxes.o rt_variant_all.o)
+OBJS := $(addprefix build/,rt_lib.o rt_lbvh.o rt_ploc.o rt_bvh.o rt_variant_spheres.o rt_variant_mesh.o rt_variant_boxes.o rt_variant_all.o)
 
 build/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
@@ -36,7 +37,11 @@ $(ORC): oracle/oracle.cpp include/rt_hip.h
 $(BENCH): tools/rtbench.cpp include/rt_hip.h $(LIB)
 	$(CXX) -O2 -std=c++17 -Wall -o $@ tools/rtbench.cpp -Lraytracer_amd -lrt_hip -Wl,-rpath,'$$ORIGIN/../raytracer_amd'
 
+# FETCH_SIZE calibration for the traversal kernels' access pattern (profiles/r02_fetch_calibration.txt)
+$(CALIB): tools/calib_fetch.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+
 clean:
-	rm -rf $(LIB) $(ORC) $(BENCH) build
+	rm -rf $(LIB) $(ORC) $(BENCH) $(CALIB) build
 
 .PHONY: all clean

@@ -5,11 +5,17 @@
 
 Workload (config.workload): BASELINE.json configs[1], "Night Spheres" 1920x1080 — BuiltinScenes.Testing with a
 seeded generator: 479 spheres + ground plane + 1 DiffuseSphereLight, depth 10, 2 light samples.
-One step = PASSES_PER_STEP (128) passes over the whole 1080p frame = 265 M samples traced, shaded and accumulated
-(two wavefront batches of 64 passes, sized for 288 GB of HBM: the deep bounces of a small batch are latency-bound launches);
-the default 2 steps are the config's 256 spp.  Scene tables, BVH and all path state are resident in HBM before the
+One step = PASSES_PER_STEP (256) passes over the whole 1080p frame = 531 M samples traced, shaded and accumulated: the
+config's 256 spp in full, as four wavefront batches of 64 passes, two in flight (batches are sized for 288 GB of HBM: the deep
+bounces of a small batch are latency-bound launches).  Scene tables, BVH and all path state are resident in HBM before the
 timed region.  With N > 1 every rank renders its own passes (rank, rank+N, ...) — weak scaling — and the timed
 region ends with the one sum-reduce of the colour buffers to rank 0 (RCCL) and the RGB24 resolve.
+
+    python bench.py --gpus N --single-process      (no torchrun)
+
+drives the N GPUs from ONE process through the library's own sharding (rt_render_opts.n_devices / device_ids: peer copies of
+the scene, one host thread per device, sums gathered over xGMI) — what a C# host would use; same workload, same JSON line.
+RT_BENCH_ONE_GPU=1 maps every shard to device 0 (rehearsal on a 1-GPU box).
 
 Adds to the JSON line: "roofline" (dominant kernel, algorithmic flops / event-timed duration, SURVEY §8d cost
 model) and "cpu_baseline" (oracle/ — the C++ restatement of RenderInternal — on the host cores, rank 0, N=1).
@@ -70,12 +76,15 @@ def main():
     ap.add_argument("--passes-per-batch", type=int, default=PASSES_PER_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-process", action="store_true", help="one process drives --gpus devices through the library's in-process sharding")
     args = ap.parse_args()
     PASSES_PER_STEP, PASSES_PER_BATCH = args.passes_per_step, args.passes_per_batch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.single_process:
+        return single_process(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
@@ -167,8 +176,9 @@ def main():
         p1 = stats_dict(job)
         pd = {k: p1[k] - p0[k] for k in p0}
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")       # PMC FETCH_SIZE/WRITE_SIZE of this workload (separate rocprofv3 passes)
-        if os.path.exists(tpath) and PASSES_PER_BATCH == 64:
+        # PMC FETCH_SIZE/WRITE_SIZE of this workload (separate rocprofv3 passes: scripts/pmc_passes.sh, scripts/pmc_traffic.py)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_traffic.json", "r01_traffic.json")) if os.path.exists(q)), "")
+        if tpath and PASSES_PER_BATCH == 64:
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tpath))["kernels"].items()}
         dominant = max(("closest", "shadow", "shade"), key=lambda k: prof[k]["total_ms"])
 
@@ -176,6 +186,8 @@ def main():
             flops, byts = algorithmic_work(pd, which)
             sec, launches = prof[which]["total_ms"] / 1e3, max(prof[which]["launches"], 1)
             tr = traffic.get("k_" + which)
+            if tr:   # FETCH_SIZE counts the coalesced path-state reads at half (scripts/pmc_traffic.py): add the other half back
+                tr += 0.5 * (32 * pd["ray_count"] if which == "closest" else 64 * pd["shadow_rays"] / LIGHT_SAMPLES) / launches
             return {"kernel": "k_" + which, "bound": "valu", "achieved": flops / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / sec / 1e12 / VALU_PEAK_TFLOPS, "traffic": tr, "launches": launches, "avg_launch_ms": prof[which]["total_ms"] / launches,
                     "algorithmic_flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": byts / launches,
@@ -214,6 +226,47 @@ def main():
     job.Dispose()
     if world > 1:
         dist.destroy_process_group()
+
+
+def single_process(args):
+    """--single-process: N devices behind one rt_render handle (RenderJob(devices=[...]))."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only trace path (no CPU fallback)")
+    import raytracer_amd as rt
+    from raytracer_amd.core import RenderOptions
+    n = args.gpus
+    devices = [0] * n if os.environ.get("RT_BENCH_ONE_GPU") == "1" else list(range(n))
+    scene = rt.BuiltinScenes.Testing()
+    t0 = time.perf_counter()
+    dev_scene = rt.DeviceScene(scene, devices[0])
+    scene_upload_s = time.perf_counter() - t0
+    total_steps = args.warmup + args.steps
+    per_step = PASSES_PER_STEP * n                      # weak scaling: every device renders PASSES_PER_STEP passes per step
+    opt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=total_steps * per_step, MaxBounceDepth=MAX_DEPTH,
+                        LightSampleCountHint=LIGHT_SAMPLES, PassesPerBatch=PASSES_PER_BATCH)
+    job = rt.RenderJob(scene, opt, device=devices[0], device_scene=dev_scene, devices=devices)
+    for i in range(args.warmup):
+        job.RenderPasses(i * per_step, per_step, 1)
+    torch.cuda.synchronize()
+    s0 = stats_dict(job)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        job.RenderPasses(i * per_step, per_step, 1)     # returns when every shard has finished its passes
+    job.UpdateImage()                                   # gathers the shards' sums onto devices[0] and resolves
+    dt = time.perf_counter() - t0
+    s1 = stats_dict(job)
+    d = {k: s1[k] - s0[k] for k in s0}
+    samples = WIDTH * HEIGHT * per_step * args.steps
+    out = {"metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "Night Spheres (BuiltinScenes.Testing, seed 0x5EED) 1920x1080, depth 10, 2 light samples, "
+                                  f"{PASSES_PER_STEP} passes per step per GPU ({args.steps * per_step} spp timed)",
+                      "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"one process, pass-sharded over devices {devices} inside the library"},
+           "mrays_per_s": {"closest": d["ray_count"] / dt / 1e6, "shadow": d["shadow_rays"] / dt / 1e6, "total": (d["ray_count"] + d["shadow_rays"]) / dt / 1e6},
+           "scene_upload_and_bvh_s": scene_upload_s, "scene_info": dev_scene.Info()}
+    print(json.dumps(out))
+    job.Dispose()
 
 
 if __name__ == "__main__":

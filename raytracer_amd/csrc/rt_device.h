@@ -554,7 +554,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
 //   node record: per axis x, y, z 24 B = (min A, min B, max A, max B, min A, min B), then (child A, child B).
 // The repeated min pair makes the ray's sign a byte offset instead of twelve selects: at +0 the lane reads (min pair, max pair) =
 // (near, far) for a ray along +axis, at +8 it reads (max pair, min pair) = (near, far) for a ray along -axis — one ds_read2_b64 per
-// axis.  The stack column holds 16-bit entries: an inner node index (< 32768) as it is, a leaf ~object as the negative number it is
+// axis.  An inner child code is index * 5, the record's offset in 16-B units.  The stack column holds 16-bit entries: an inner code (< 32768) as it is, a leaf ~object as the negative number it is
 // (ds_read_i16 sign-extends it back), so push and pop are one LDS instruction each, no encoding.
 constexpr uint32_t LDS_NODE_BYTES = 80;
 struct LdsTree {
@@ -564,7 +564,7 @@ struct LdsTree {
     const char* nodes; const float4* sph;
     short* stack; int stride;
     template <class Box> RT_FN void planes(const SceneDev&, int i, const Box& box, NodePlanes& p, int2& ch) const {
-        const char* n = nodes + (uint32_t)i * LDS_NODE_BYTES;
+        const char* n = nodes + ((uint32_t)i << 4);              // i = the record's offset in 16-B units (rt_scene_create writes inner child codes that way; the root is 0)
         const char* ax = n + box.o8x; const char* ay = n + 24 + box.o8y; const char* az = n + 48 + box.o8z;
         p.nx = *(const v2f*)ax; p.fx = *(const v2f*)(ax + 8);
         p.ny = *(const v2f*)ay; p.fy = *(const v2f*)(ay + 8);

@@ -18,6 +18,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_bvh.h"
 namespace rtlbvh { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, std::string& err); }
+namespace rtploc { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, uint32_t* rounds, std::string& err); }
 #define RT_KERNELS_COMMON
 #include "rt_kernels.h"
 
@@ -116,7 +117,8 @@ void bind_scene_pointers(rt_scene* s) {
 // cap rt_scene_create admits (80 KB), never to one scene's need: a second scene cannot lower the first one's limit.
 constexpr size_t LDS_TREE_CAP = 80 * 1024;
 int allow_big_lds(const KernelSet* ks) {
-    const void* fns[5] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact};
+    const void* fns[6] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
+                          (const void*)ks->shadow_persistent_lds};
     for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
     return RT_OK;
 }
@@ -306,11 +308,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rtbvh::Box b; for (int a = 0; a < 3; a++) { b.mn[a] = o.aabb_min[a]; b.mx[a] = o.aabb_max[a]; }
         boxes.push_back(b); box_obj.push_back(i);
     }
-    // Builder: binned SAH on the host (rt_bvh.cpp, subtrees on all host threads: 5 M triangles in well under a second), or, with
-    // RT_HIP_BVH=device, Morton order + Karras links + bottom-up refit on the device (rt_lbvh.hip): tens of milliseconds, but rays
-    // then do 15 % more box tests (C4: 898 -> 711 Msamples/s), so it is for scenes rebuilt more often than they are rendered.
-    bool device_build = false;
-    if (const char* e = getenv("RT_HIP_BVH")) device_build = !strcmp(e, "device") && boxes.size() >= 2;
+    // Builder: binned SAH on the host (rt_bvh.cpp, subtrees on all host threads: 5 M triangles in well under a second), or on the
+    // device: RT_HIP_BVH=ploc, agglomerative clustering by surface area in Morton windows (rt_ploc.hip: SAH quality in tens of
+    // milliseconds), or RT_HIP_BVH=device, Morton order + Karras links + bottom-up refit (rt_lbvh.hip: the fastest build, but rays
+    // then do 15 % more box tests, C4: 898 -> 711 Msamples/s).  RT_HIP_BVH=host forces the host builder.
+    bool device_build = false, ploc = false;
+    if (const char* e = getenv("RT_HIP_BVH")) { ploc = !strcmp(e, "ploc"); device_build = (ploc || !strcmp(e, "device")) && boxes.size() >= 2; }
     rtbvh::BuildResult bvh;
     if (!device_build) bvh = rtbvh::build(boxes, box_obj);
 
@@ -397,7 +400,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         n_nodes = boxes.size() - 1;
         HIP_TRY(s->nodes.alloc(n_nodes * sizeof(Node)));
         std::string err;
-        int brc = rtlbvh::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, err);
+        uint32_t rounds = 0;
+        int brc = ploc ? rtploc::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, &rounds, err)
+                       : rtlbvh::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, err);
         if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "device BVH build: %s", err.c_str());
     } else UP(nodes, nodes);
     s->device_build = device_build;
@@ -475,7 +480,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const size_t image_bytes = nn * LDS_NODE_BYTES + no * 16;
         const size_t need = image_bytes + (size_t)s->stack_depth * LDS_BLOCK_CLOSEST * sizeof(unsigned short);
         const char* no_lds = getenv("RT_HIP_NO_LDS_TREE");
-        if (all_spheres && !s->dev.n_list_pairs && nn < 32768 && no < 32768 && need <= LDS_TREE_CAP && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+        if (all_spheres && !s->dev.n_list_pairs && nn * (LDS_NODE_BYTES / 16) < 32768 && no < 32768 && need <= LDS_TREE_CAP && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
             // node record (rt_device.h LdsTree): per axis (min A, min B, max A, max B, min A, min B), then (child A, child B)
             static_assert(LDS_NODE_BYTES == 80 && LDS_NODE_BYTES % 16 == 0, "LDS node layout");
             std::vector<float4> img(image_bytes / 16, make_float4(0, 0, 0, 0));
@@ -486,7 +491,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                     float* ax = rec + 6 * a;
                     ax[0] = h.q[2 * a]; ax[1] = h.q[2 * a + 1]; ax[2] = h.q[6 + 2 * a]; ax[3] = h.q[6 + 2 * a + 1]; ax[4] = ax[0]; ax[5] = ax[1];
                 }
-                memcpy(rec + 18, &h.childA, 4); memcpy(rec + 19, &h.childB, 4);
+                // an inner child is stored as its record's offset in 16-B units (index * 5): the lane's address is a shift, not a 32-bit multiply
+                const int32_t cA = h.childA >= 0 ? h.childA * (int32_t)(LDS_NODE_BYTES / 16) : h.childA, cB = h.childB >= 0 ? h.childB * (int32_t)(LDS_NODE_BYTES / 16) : h.childB;
+                memcpy(rec + 18, &cA, 4); memcpy(rec + 19, &cB, 4);
             }
             float4* sp = img.data() + nn * (LDS_NODE_BYTES / 16);
             for (size_t i = 0; i < no; i++) if (d->objects[i].type == RT_HIT_SPHERE) sp[i] = spheres[d->objects[i].index];
@@ -849,7 +856,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : (s->persistent_shadow == 1 && ks->shadow_persistent_lds) ? ks->shadow_persistent_lds : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on

@@ -14,8 +14,11 @@ Per config: Msamples/s and Mrays/s over `passes` passes (two batch slots in flig
                       box 70/112, capsule 60/32, disk 42/48, cylinder 60/32), plane 12/24 for the unbounded InfinitePlane tests
     frac_valu = flops / time / 157.3 TFLOP/s (FP32 vector peak; the kernels are built -ffp-contract=off, so half of it is their ceiling)
     frac_hbm_model = bytes / time / 8 TB/s — the §8d byte model counts every node and primitive fetch, cached or not
-    frac_hbm_pmc   = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches / time / 8 TB/s when --traffic names a PMC file for this config
-                     (scripts/pmc_passes.sh with BENCH_CMD="python3 scripts/run_configs.py cN --short", then scripts/pmc_traffic.py)
+    frac_hbm_pmc   = ((FETCH_SIZE + WRITE_SIZE) * 1024 per launch + half the coalesced state reads) / time / 8 TB/s when --traffic names a
+                     PMC file for this config (scripts/pmc_passes.sh with BENCH_CMD="python3 scripts/run_configs.py cN --short", then
+                     scripts/pmc_traffic.py, which explains the calibration: gathers of 64-B node records are counted in full, coalesced
+                     16-B-per-lane streams at half — so 16 B per bounce ray / 32 B per shadow request are added back here).  The counters
+                     sit on the L2's memory side: Infinity Cache hits are included, it is an upper bound on HBM bytes.
 `roofline.frac` is frac_valu for scenes whose tree fits the caches (c1, c2, c3, c5: <= 6.4 MB of nodes) and frac_hbm_pmc (falling back
 to the model) for c4, whose 320 MB of nodes + 320 MB of triangles do not."""
 import json, os, sys, time
@@ -113,8 +116,12 @@ def main():
         tname = next((k for k in tr if k.startswith("k_" + dominant)), None)
         hbm_bound = dev.Info()["n_nodes"] * 64 > (64 << 20)        # the tree alone exceeds the 4 MB L2s x 8 and most of the 256 MB Infinity Cache's share
         if tname:
-            per_launch = tr[tname]["hbm_bytes_per_launch"]
+            # the half of the coalesced path-state reads that FETCH_SIZE leaves out (k_closest: 2 float4 per ray; k_shadow: 3 float4 per request + its 16-B target)
+            n_light_rays = max(ls * max(len(sc.Lights), 1), 1)
+            left_out = 0.5 * (32 * r["rays"] if dominant == "closest" else 64 * r["rays"] / n_light_rays) / max(r["launches"], 1)
+            per_launch = tr[tname]["hbm_bytes_per_launch"] + left_out
             r["traffic"] = per_launch
+            r["traffic_note"] = "L2 memory-side bytes per launch (Infinity Cache hits included): FETCH_SIZE + WRITE_SIZE, + the uncounted half of the coalesced state reads"
             r["pmc_gbs"] = per_launch * r["launches"] / (r["total_ms"] / 1e3) / 1e9
             r["frac_hbm_pmc"] = r["pmc_gbs"] / HBM_PEAK_GBS
         else:
