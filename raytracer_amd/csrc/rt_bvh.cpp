@@ -1,4 +1,4 @@
-// rt_bvh.cpp — binned-SAH BVH2 builder (see rt_bvh.h).
+// rt_bvh.cpp — SAH BVH2 builder (see rt_bvh.h): 16 bins per axis for big nodes, every split position for nodes of <= 4096 objects.
 #include "rt_bvh.h"
 #include <algorithm>
 #include <cmath>
@@ -12,6 +12,10 @@ namespace rtbvh {
 namespace {
 
 constexpr int kBins = 16;
+#ifndef RT_BVH_SWEEP_MAX
+#define RT_BVH_SWEEP_MAX 4096
+#endif
+constexpr uint32_t kSweepMax = RT_BVH_SWEEP_MAX;   // nodes of at most this many objects try every split position (full-sweep SAH), not 15 bin borders
 constexpr uint32_t kMaxSahDepth = 40;   // beyond this, split at the median so the traversal stack stays short
 
 // `node` = index the subtree's root will get: with one object per leaf a subtree over c objects has exactly c-1 inner nodes, so the
@@ -112,7 +116,33 @@ BuildResult build(const std::vector<Box>& boxes, const std::vector<uint32_t>& ob
         uint32_t mid = w.begin + cnt / 2;
         bool have_split = false;
         Box child_bounds[2]; bool have_child_bounds = false;
-        if (cnt > 2 && w.depth < kMaxSahDepth) {
+        if (cnt > 2 && cnt <= kSweepMax && w.depth < kMaxSahDepth) {
+            // full sweep: per axis sort by centroid (ties by object index: deterministic), cost of every prefix | suffix split
+            std::vector<uint32_t> ids(order.begin() + w.begin, order.begin() + w.end), best_ids;
+            std::vector<double> right_area(cnt);
+            double best_cost = std::numeric_limits<double>::infinity(); uint32_t best_k = 0; Box best_l = empty_box(), best_r = empty_box();
+            for (int a = 0; a < 3; a++) {
+                std::sort(ids.begin(), ids.end(), [&](uint32_t l, uint32_t r) { return cen[a][l] < cen[a][r] || (cen[a][l] == cen[a][r] && l < r); });
+                Box acc = empty_box();
+                for (uint32_t k = cnt - 1; k > 0; k--) { grow(acc, boxes[ids[k]]); right_area[k] = half_area(acc); }
+                acc = empty_box();
+                bool better = false; uint32_t kk = 0; Box lb = empty_box();
+                for (uint32_t k = 1; k < cnt; k++) {          // left = ids[0..k), right = ids[k..cnt)
+                    grow(acc, boxes[ids[k - 1]]);
+                    const double cost = half_area(acc) * k + right_area[k] * (cnt - k);
+                    if (cost < best_cost) { best_cost = cost; kk = k; lb = acc; better = true; }
+                }
+                if (better) {
+                    best_k = kk; best_l = lb; best_ids = ids;
+                    best_r = empty_box(); for (uint32_t k = kk; k < cnt; k++) grow(best_r, boxes[ids[k]]);
+                }
+            }
+            if (best_k > 0) {
+                std::copy(best_ids.begin(), best_ids.end(), order.begin() + w.begin);
+                mid = w.begin + best_k; have_split = true;
+                child_bounds[0] = best_l; child_bounds[1] = best_r; have_child_bounds = true;
+            }
+        } else if (cnt > 2 && w.depth < kMaxSahDepth) {
             float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
             {
                 float pmn[16][3], pmx[16][3];

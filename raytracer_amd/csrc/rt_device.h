@@ -526,6 +526,7 @@ struct HbmTree {
     static constexpr bool vote = RT_TRAV_VOTE;
     static constexpr bool any_order = true;
     static constexpr bool list = true;       // scenes of a handful of objects are walked as a list (list_closest)
+    static constexpr bool may_have_empty_child = true;       // the root of a one-object tree
     int* stack; int stride;
     template <class Box> RT_FN void planes(const SceneDev& sc, int i, const Box& box, NodePlanes& p, int2& ch) const {
         const Node* np = sc.nodes + i;
@@ -560,6 +561,7 @@ constexpr uint32_t LDS_NODE_BYTES = 80;
 struct LdsTree {
     static constexpr bool any_order = false;
     static constexpr bool list = false;      // (the host never pairs the LDS tree with an object list: keeps these kernels' registers)
+    static constexpr bool may_have_empty_child = false;      // rt_scene_create puts a tree in LDS only if it has two objects or more: every node is full
     static constexpr bool vote = RT_LDS_VOTE;      // rays of equal cost: the votes only cost instructions here
     const char* nodes; const float4* sph;
     short* stack; int stride;
@@ -604,11 +606,11 @@ RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Box& box, float
     bool hA, hB;
     if (ANY) {     // a hit exactly on a (grown) box face must never be culled: exit >= entry
         const float hiA = __builtin_fminf(exA, kMax), hiB = __builtin_fminf(exB, kMax);
-        hA = (ch.x != CHILD_EMPTY) && !(hiA < enA);
-        hB = (ch.y != CHILD_EMPTY) && !(hiB < enB);
+        hA = (!Tree::may_have_empty_child || ch.x != CHILD_EMPTY) && !(hiA < enA);
+        hB = (!Tree::may_have_empty_child || ch.y != CHILD_EMPTY) && !(hiB < enB);
     } else {
-        hA = (ch.x != CHILD_EMPTY) && slab_hit(enA, exA, kMax);
-        hB = (ch.y != CHILD_EMPTY) && slab_hit(enB, exB, kMax);
+        hA = (!Tree::may_have_empty_child || ch.x != CHILD_EMPTY) && slab_hit(enA, exA, kMax);
+        hB = (!Tree::may_have_empty_child || ch.y != CHILD_EMPTY) && slab_hit(enB, exB, kMax);
         box_miss += (hA ? 0u : 1u) + (hB ? 0u : 1u);
     }
     int next = ch.x; bool pop = false;

@@ -480,7 +480,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const size_t image_bytes = nn * LDS_NODE_BYTES + no * 16;
         const size_t need = image_bytes + (size_t)s->stack_depth * LDS_BLOCK_CLOSEST * sizeof(unsigned short);
         const char* no_lds = getenv("RT_HIP_NO_LDS_TREE");
-        if (all_spheres && !s->dev.n_list_pairs && nn * (LDS_NODE_BYTES / 16) < 32768 && no < 32768 && need <= LDS_TREE_CAP && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
+        if (all_spheres && boxes.size() >= 2 && !s->dev.n_list_pairs && nn * (LDS_NODE_BYTES / 16) < 32768 && no < 32768 && need <= LDS_TREE_CAP && !(no_lds && no_lds[0] == '1') && !(force && !strcmp(force, "generic"))) {
             // node record (rt_device.h LdsTree): per axis (min A, min B, max A, max B, min A, min B), then (child A, child B)
             static_assert(LDS_NODE_BYTES == 80 && LDS_NODE_BYTES % 16 == 0, "LDS node layout");
             std::vector<float4> img(image_bytes / 16, make_float4(0, 0, 0, 0));
