@@ -766,15 +766,14 @@ struct KernelSet {
     void (*shadow_lds_exact)(SceneDev, RenderDev, uint32_t);
     void (*closest_lds)(SceneDev, RenderDev, uint32_t);
     void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
-    void (*shadow_persistent_lds)(SceneDev, RenderDev, uint32_t);     // experiment hook (RT_HIP_PERSISTENT_SHADOW=1 on an LDS-tree scene)
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
     void (*trace_any_lds)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
                 k_closest_persistent<C, false>, k_shadow_persistent<C, false>, k_shadow<C, false, true>, k_shadow_persistent<C, false, true>, nullptr,
-                nullptr, nullptr, nullptr, nullptr, nullptr};
-    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_persistent_lds = k_shadow_persistent<C, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+                nullptr, nullptr, nullptr, nullptr};
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }
 

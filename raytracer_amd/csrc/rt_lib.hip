@@ -117,8 +117,7 @@ void bind_scene_pointers(rt_scene* s) {
 // cap rt_scene_create admits (80 KB), never to one scene's need: a second scene cannot lower the first one's limit.
 constexpr size_t LDS_TREE_CAP = 80 * 1024;
 int allow_big_lds(const KernelSet* ks) {
-    const void* fns[6] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
-                          (const void*)ks->shadow_persistent_lds};
+    const void* fns[5] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact};
     for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
     return RT_OK;
 }
@@ -856,7 +855,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : (s->persistent_shadow == 1 && ks->shadow_persistent_lds) ? ks->shadow_persistent_lds : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on
