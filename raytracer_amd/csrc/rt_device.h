@@ -597,8 +597,26 @@ struct LdsTree {
 // One inner-node step: test both child boxes against [kMin, kMax] (kMax = the best K so far for closest hit), continue with
 // the nearer hit child, push the other, pop when neither is hit; a leaf met while no leaf is parked is parked in `pend` and
 // the descent goes on.  ANY = any-hit rule: closed box interval, no near/far ordering.
+// The traversal stack: its newest entry lives in a register, the rest in the lane's LDS column.  A pop hands out the register at
+// once and refills it from LDS for the NEXT pop, so the LDS round trip is off the node-to-node critical path (RT_STACK_TOP=0:
+// every entry in LDS, the layout of round 1).  Slot sp of the column holds the entry below the register; slot 0 is never read back.
+#ifndef RT_STACK_TOP
+#define RT_STACK_TOP 1
+#endif
+struct Stk { int sp, top; };
+RT_FN Stk stk_empty() { Stk s; s.sp = 0; s.top = TRAV_DONE; return s; }
+template <class Tree> RT_FN void stk_push(const Tree& tree, Stk& s, int v) {
+    if (RT_STACK_TOP) { tree.push(s.sp, s.top); s.top = v; } else tree.push(s.sp, v);
+    s.sp++;
+}
+template <class Tree> RT_FN int stk_pop(const Tree& tree, Stk& s) {      // TRAV_DONE when empty
+    if (!s.sp) return TRAV_DONE;
+    s.sp--;
+    if (RT_STACK_TOP) { const int v = s.top; s.top = tree.pop(s.sp); return v; }
+    return tree.pop(s.sp);
+}
 template <bool ANY, class Tree, class Box>
-RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Box& box, float kMin, float kMax, int& cur, int& pend, int& sp, uint32_t& box_miss) {
+RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Box& box, float kMin, float kMax, int& cur, int& pend, Stk& sp, uint32_t& box_miss) {
     NodePlanes pl; int2 ch;
     tree.planes(sc, cur, box, pl, ch);
     float enA, exA, enB, exB;
@@ -619,27 +637,27 @@ RT_FN void node_step(const SceneDev& sc, const Tree& tree, const Box& box, float
         // origin ends the ray at once (100 k spheres + 64 lights: 66 -> 53 box tests per shadow ray, k_shadow 659 -> 521 ms), and costs
         // its two selects in small ones (Cornell +5 %), so the host sets the flag by tree size.
         const bool bFirst = (!ANY || (Tree::any_order && sc.any_near_first)) && (enB < enA);
-        tree.push(sp, bFirst ? ch.x : ch.y); sp++;
+        stk_push(tree, sp, bFirst ? ch.x : ch.y);
         next = bFirst ? ch.y : ch.x;
     } else if (hB) next = ch.y;
     else if (!hA) pop = true;
     if (!pop && next < 0 && pend == TRAV_DONE) { pend = next; pop = true; }   // park one leaf, keep descending
     if (pop) {
-        if (sp) { sp--; next = tree.pop(sp); } else next = TRAV_DONE;
+        next = stk_pop(tree, sp);
         if (next < 0 && next != TRAV_DONE && pend == TRAV_DONE) {          // the popped entry is a leaf and the parking slot is free
             pend = next;
-            if (sp) { sp--; next = tree.pop(sp); } else next = TRAV_DONE;
+            next = stk_pop(tree, sp);
         }
     }
     cur = next;                                                            // invariant on return: a leaf in `cur` implies a leaf in `pend`
 }
 // After the parked leaf has been tested: a second leaf waiting in `cur` takes its place and the descent resumes from the stack.
 template <class Tree>
-RT_FN void leaf_advance(const Tree& tree, int& cur, int& pend, int& sp) {
+RT_FN void leaf_advance(const Tree& tree, int& cur, int& pend, Stk& sp) {
     pend = TRAV_DONE;
     if (cur < 0 && cur != TRAV_DONE) {
         pend = cur;
-        if (sp) { sp--; cur = tree.pop(sp); } else cur = TRAV_DONE;
+        cur = stk_pop(tree, sp);
     }
 }
 
@@ -769,7 +787,7 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
     if (Tree::list && sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
     else if (sc.n_nodes) {
         const ClosestBox box = closest_box(r);
-        int sp = 0, cur = 0, pend = TRAV_DONE;
+        Stk sp = stk_empty(); int cur = 0, pend = TRAV_DONE;
         for (;;) {
             if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); } }
             else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); }   // every lane does box tests here
@@ -815,7 +833,7 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
     for (;;) {                                                   // once, or twice (see any_box)
         if (Tree::list && sc.n_list_pairs) { if (list_any<C>(sc, r, box, kMin, kMax, cnt)) return true; }
         else {
-            int sp = 0, cur = 0, pend = TRAV_DONE;
+            Stk sp = stk_empty(); int cur = 0, pend = TRAV_DONE;
             uint32_t unused = 0;
             for (;;) {
                 if constexpr (Tree::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); } }

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
     ClosestBox box = closest_box(r);
     Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
-    int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
+    int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
     for (;;) {
         // ---- store / fetch for every lane that is not traversing
         const unsigned long long idle = __ballot(cur == TRAV_DONE && pend == TRAV_DONE);
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
                 my_j = j; rays++;
                 best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
-                sp = 0; active = true;
+                sp = stk_empty(); active = true;
                 if (!ray_has_nan(r)) {
                     for (uint32_t i = 0; i < sc.n_unbounded; i++) {
                         uint32_t obj = sc.unbounded[i], code = sc.obj_code[obj];
@@ -573,14 +573,14 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     AnyBox box = make_any_box(r, 0.0f);
     uint32_t unused = 0;
     float kMin = 0, kMax = 0;
-    int cur = TRAV_DONE, pend = TRAV_DONE, sp = 0;
+    int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
     for (;;) {
         bool fetched = false;
         if (cur == TRAV_DONE && pend == TRAV_DONE) {
             if (flying && again && !occluded) {                                 // ---- unoccluded in the boxes as they are: look again in the grown ones
                 box = any_box(sc, r, kMax, rd.any_cap, 1, again);
-                cur = 0; sp = 0;
+                cur = 0; sp = stk_empty();
             } else if (flying) {                                                // ---- account for the finished ray
                 flying = false;
                 const rt_light* l = sc.lights + li;
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                     }
                 }
                 again = false;
-                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = 0; }
+                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = stk_empty(); }
             }
         }
         next += (uint32_t)__popcll(__ballot(fetched));
