@@ -55,7 +55,7 @@ public static unsafe class RtHip
 {
 	private const string Lib = "rt_hip"; // librt_hip.so next to the assembly, or on LD_LIBRARY_PATH
 
-	public const uint AbiVersion = 2;            // RT_ABI_VERSION
+	public const uint AbiVersion = 3;            // RT_ABI_VERSION
 	public const uint NoHit      = 0xFFFFFFFFu;  // RT_NO_HIT
 	public const int  MaxDevices = 16;           // RT_MAX_DEVICES
 	public const uint RenderExactLightSampling = 1u;   // RT_RENDER_EXACT_LIGHT_SAMPLING
@@ -150,6 +150,7 @@ public static unsafe class RtHip
 		public ulong PixelsRendered; public ulong PassesRendered; public ulong MaterialScatterCount; public ulong MaterialAbsorbedCount; public ulong AabbMisses;
 		public ulong HittableMisses; public ulong HittableIntersections; public ulong SkyRays; public ulong BounceLimitExceeded; public ulong RayCount;
 		public ulong ShadowRays; public ulong NodeVisits; public ulong PrimTests; public ulong ShadowNodeVisits; public ulong ShadowPrimTests;
+		public ulong NormalsWrongMagnitude; public ulong UvInvalid;
 		public fixed ulong RayDepthCounts[64];
 	}
 
@@ -353,6 +354,9 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 		rs.MaterialAbsorbedCount = s.MaterialAbsorbedCount; rs.SkyRays = s.SkyRays; rs.BounceLimitExceeded = s.BounceLimitExceeded; rs.RayCount = s.RayCount;
 		rs.AabbMisses = s.AabbMisses; rs.HittableMisses = s.HittableMisses; rs.HittableIntersections = s.HittableIntersections;   // RenderStats.cs: the three BVH counters the GUI panels show
 		for (int d = 0; d < 64; d++) if (s.RayDepthCounts[d] != 0) rs.RayDepthCounts[d] = s.RayDepthCounts[d];
+		// the warn-only validator rules (RenderJob.cs:588-607): the device sums over objects, so the totals are filed under the scene itself
+		if (s.NormalsWrongMagnitude != 0) GraphicsValidator.Errors.GetOrAdd(GraphicsErrorType.NormalsWrongMagnitude, _ => new())[job.Scene] = s.NormalsWrongMagnitude;
+		if (s.UvInvalid != 0) GraphicsValidator.Errors.GetOrAdd(GraphicsErrorType.UVInvalid, _ => new())[job.Scene] = s.UvInvalid;
 	}
 
 	private static RtHip.Camera FlattenCamera(Camera c)

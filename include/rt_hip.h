@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef struct rt_scene  rt_scene;   /* opaque: flattened Scene + BVH on one device */
 typedef struct rt_render rt_render;  /* opaque: one RenderJob's device state */
@@ -340,6 +340,11 @@ typedef struct rt_stats {
     uint64_t prim_tests;             /* T: primitive tests during closest-hit traversal */
     uint64_t shadow_node_visits;     /* V for any-hit traversal */
     uint64_t shadow_prim_tests;      /* T for any-hit traversal */
+    uint64_t normals_wrong_magnitude;/* closest hits whose normal fails CheckVectorNormalized (GraphicsValidator.cs:52-60,
+                                        |n.n - 1| > 0.01; RenderJob.cs:588-598 logs and counts it, changes nothing) — e.g. an InfinitePlane built with a normal
+                                        that is not a unit vector (InfinitePlane.cs:20-25 keeps it as given).  Summed over objects. */
+    uint64_t uv_invalid;             /* CheckUVCoordValid fails (GraphicsValidator.cs:62-66; RenderJob.cs:600-607 records GraphicsErrorType.UVInvalid): closest hits with a UV outside [0, 1]^2.
+                                        Counted where the device computes UVs: debug-visualisation renders (every hit); 0 otherwise */
     uint64_t ray_depth_counts[RT_DEPTH_HIST_SIZE]; /* RenderStats.RayDepthCounts (:458); depths >= 63 land in [63] */
 } rt_stats;
 

@@ -551,11 +551,12 @@ struct Medium : Hittable {
 struct Stats {
     uint64_t aabbMisses = 0, hittableMisses = 0, hittableIntersections = 0, rayCount = 0, shadowRays = 0;
     uint64_t skyRays = 0, bounceLimit = 0, scatter = 0, absorbed = 0, pixels = 0;
+    uint64_t normalsWrong = 0, uvInvalid = 0;       // GraphicsValidator.RecordError counts, summed over objects (RenderJob.cs:597, :606)
     uint64_t depth[RT_DEPTH_HIST_SIZE] = {};
     void add(const Stats& o) {
         aabbMisses += o.aabbMisses; hittableMisses += o.hittableMisses; hittableIntersections += o.hittableIntersections;
         rayCount += o.rayCount; shadowRays += o.shadowRays; skyRays += o.skyRays; bounceLimit += o.bounceLimit;
-        scatter += o.scatter; absorbed += o.absorbed; pixels += o.pixels;
+        scatter += o.scatter; absorbed += o.absorbed; pixels += o.pixels; normalsWrong += o.normalsWrong; uvInvalid += o.uvInvalid;
         for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) depth[i] += o.depth[i];
     }
 };
@@ -870,6 +871,9 @@ static Found TryFindClosestHit(const SceneData& sc, const Ray& ray, float kMin, 
         best.obj = m.index; best.hit = h;
     }
     if (!best.ok()) return {};
+    // the two warn-only rules: CheckVectorNormalized (GraphicsValidator.cs:52-60), CheckUVCoordValid (GraphicsValidator.cs:62-66); RenderJob.cs:588-607 logs, counts, changes nothing
+    if (!(!(std::fabs(LengthSquared(best.hit.Normal) - 1.0f) > 0.01f))) st.normalsWrong++;
+    if (!((best.hit.U >= 0.0f) && (best.hit.U <= 1.0f) && (best.hit.V >= 0.0f) && (best.hit.V <= 1.0f))) st.uvInvalid++;
     // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 ; RenderJob.cs:609-614
     if (!((best.hit.K >= kMin) && (best.hit.K <= kMax))) return {};
     return best;
@@ -1363,6 +1367,7 @@ int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, ui
         stats_out->material_scatter_count = tot.scatter; stats_out->material_absorbed_count = tot.absorbed;
         stats_out->aabb_misses = tot.aabbMisses; stats_out->hittable_misses = tot.hittableMisses;
         stats_out->hittable_intersections = tot.hittableIntersections; stats_out->sky_rays = tot.skyRays;
+        stats_out->normals_wrong_magnitude = tot.normalsWrong; stats_out->uv_invalid = tot.uvInvalid;
         stats_out->bounce_limit_exceeded = tot.bounceLimit; stats_out->ray_count = tot.rayCount; stats_out->shadow_rays = tot.shadowRays;
         for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) stats_out->ray_depth_counts[i] = tot.depth[i];
     }

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")     # RT_HIP_LIB: A/B a differently built library
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_MAX_DEVICES = 16
 RENDER_EXACT_LIGHT_SAMPLING = 1
 RENDER_EXACT_OCCLUSION = 2
@@ -118,7 +118,8 @@ class RenderOpts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pixels_rendered", "passes_rendered", "material_scatter_count", "material_absorbed_count", "aabb_misses",
                                           "hittable_misses", "hittable_intersections", "sky_rays", "bounce_limit_exceeded", "ray_count",
-                                          "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests")] + \
+                                          "shadow_rays", "node_visits", "prim_tests", "shadow_node_visits", "shadow_prim_tests",
+                                          "normals_wrong_magnitude", "uv_invalid")] + \
                [("ray_depth_counts", C.c_uint64 * RT_DEPTH_HIST_SIZE)]
 
     def as_dict(self):

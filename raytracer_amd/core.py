@@ -267,4 +267,6 @@ class RenderStats:                 # Core/RenderStats.cs:12-93 (+ the counters t
     PrimTests: int = 0
     ShadowNodeVisits: int = 0
     ShadowPrimTests: int = 0
+    NormalsWrongMagnitude: int = 0   # GraphicsValidator.Errors[NormalsWrongMagnitude] summed over objects (RenderJob.cs:588-598)
+    UVInvalid: int = 0               # ...[UVInvalid] (:600-607); counted in debug-visualisation renders
     RayDepthCounts: List[int] = field(default_factory=lambda: [0] * 64)

@@ -24,6 +24,7 @@ constexpr int BLOCK = 256;
 enum StatSlot : int {
     ST_RAYS = 0, ST_SHADOW_RAYS, ST_NODES, ST_PRIMS, ST_SH_NODES, ST_SH_PRIMS, ST_SKY, ST_LIMIT, ST_SCATTER, ST_ABSORBED, ST_SAMPLES,
     ST_BOX_MISS, ST_PRIM_HIT,        // AabbMisses, HittableIntersections (HittableMisses = ST_PRIMS - ST_PRIM_HIT)
+    ST_NORMAL_WARN, ST_UV_WARN,      // the warn-only GraphicsValidator rules (RenderJob.cs:588-607)
     ST_DEPTH0, ST_COUNT = ST_DEPTH0 + RT_DEPTH_HIST_SIZE
 };
 
@@ -295,7 +296,7 @@ template <class C, bool VIS = false>
 __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
-    unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0;
+    unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0, n_warn = 0, uv_warn = 0;
     __shared__ uint32_t wcnt[2][SHADE_ITEMS][BLOCK / 64];
     __shared__ uint32_t bases[2];
     constexpr uint32_t TILE = SHADE_ITEMS * BLOCK;
@@ -359,6 +360,8 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
             } else {
                 RngKey key = path_key(rd, id);
                 HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth);
+                if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) n_warn++;                      // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
+                if constexpr (VIS) { if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) uv_warn++; }   // CheckUVCoordValid
                 const rt_material* m = sc.materials + h.mat;
                 uint32_t prev = unpack_mat(a3.y), first = unpack_mat(a3.y >> 16);
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
@@ -463,10 +466,10 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
       __syncthreads();       // wcnt / bases are reused by the next tile
     }
     {   // (RenderJob.cs:458: a miss at depth d ends a path of maxDepthReached d-1, the bounce limit one of depth d; a primary miss is not counted)
-        const int slot[6] = {ST_SKY, ST_LIMIT, ST_SCATTER, ST_SAMPLES, ST_DEPTH0 + (int)min(depth > 0 ? depth - 1 : 0u, (uint32_t)RT_DEPTH_HIST_SIZE - 1),
-                             ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1)};
-        const unsigned long long v[6] = {sky, limit, scat, samples, depth > 0 ? hist_miss : 0ull, limit};
-        stat_add_block<6>(rd.stats, slot, v);
+        const int slot[8] = {ST_SKY, ST_LIMIT, ST_SCATTER, ST_SAMPLES, ST_DEPTH0 + (int)min(depth > 0 ? depth - 1 : 0u, (uint32_t)RT_DEPTH_HIST_SIZE - 1),
+                             ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1), ST_NORMAL_WARN, ST_UV_WARN};
+        const unsigned long long v[8] = {sky, limit, scat, samples, depth > 0 ? hist_miss : 0ull, limit, n_warn, uv_warn};
+        stat_add_block<8>(rd.stats, slot, v);
     }
 }
 

@@ -982,6 +982,7 @@ static int stats_single(rt_render* r, rt_stats* out) {
     out->aabb_misses = h[ST_BOX_MISS]; out->hittable_intersections = h[ST_PRIM_HIT]; out->hittable_misses = h[ST_PRIMS] - h[ST_PRIM_HIT];
     out->sky_rays = h[ST_SKY]; out->bounce_limit_exceeded = h[ST_LIMIT]; out->ray_count = h[ST_RAYS]; out->shadow_rays = h[ST_SHADOW_RAYS];
     out->node_visits = h[ST_NODES]; out->prim_tests = h[ST_PRIMS]; out->shadow_node_visits = h[ST_SH_NODES]; out->shadow_prim_tests = h[ST_SH_PRIMS];
+    out->normals_wrong_magnitude = h[ST_NORMAL_WARN]; out->uv_invalid = h[ST_UV_WARN];
     for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) out->ray_depth_counts[i] = h[ST_DEPTH0 + i];
     return RT_OK;
 }

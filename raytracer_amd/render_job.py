@@ -273,6 +273,7 @@ class RenderJob:
         s.AabbMisses, s.HittableMisses, s.HittableIntersections = st.aabb_misses, st.hittable_misses, st.hittable_intersections
         s.SkyRays, s.BounceLimitExceeded, s.RayCount, s.ShadowRays = st.sky_rays, st.bounce_limit_exceeded, st.ray_count, st.shadow_rays
         s.NodeVisits, s.PrimTests, s.ShadowNodeVisits, s.ShadowPrimTests = st.node_visits, st.prim_tests, st.shadow_node_visits, st.shadow_prim_tests
+        s.NormalsWrongMagnitude, s.UVInvalid = st.normals_wrong_magnitude, st.uv_invalid
         s.RayDepthCounts = [int(x) for x in st.ray_depth_counts]
         return s
 

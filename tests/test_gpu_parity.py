@@ -138,6 +138,9 @@ def test_image_parity(pairs, name, w, h, passes, depth, ls, exact):
     assert st.PassesRendered == passes
     if exact:
         assert (st.RayCount, st.ShadowRays, st.MaterialScatterCount) == (rst["ray_count"], rst["shadow_rays"], rst["material_scatter_count"])
+        # the warn-only validator rule on normals (RenderJob.cs:588-598): the Zoo's ground plane has the normal (0, 2, 0), kept as given
+        assert st.NormalsWrongMagnitude == rst["normals_wrong_magnitude"]
+        assert (st.NormalsWrongMagnitude > 0) == (name == "Zoo")
     assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] + 2
     assert abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"] + 2
     assert st.SkyRays + st.BounceLimitExceeded == st.PixelsRendered
@@ -218,8 +221,12 @@ def test_debug_visualisations_match_the_oracle(pairs, name, vis):
     sc, flat, dev, orc = pairs(name)
     opt = RenderOptions(RenderWidth=96, RenderHeight=54, Passes=3, MaxBounceDepth=6, LightSampleCountHint=2, Seed=77, DebugVisualisation=vis)
     job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
-    got, n = job.ReadAccum(); job.Dispose()
-    ref, _ = orc.render(opt, threads=8)
+    got, n = job.ReadAccum(); st = job.UpdateStats(); job.Dispose()
+    ref, rst = orc.render(opt, threads=8)
+    # the warn-only validator rules (RenderJob.cs:588-607) are counted for every closest hit of a visualisation render, UVs included
+    assert (st.NormalsWrongMagnitude, st.UVInvalid) == (rst["normals_wrong_magnitude"], rst["uv_invalid"]), (st.NormalsWrongMagnitude, st.UVInvalid, rst["normals_wrong_magnitude"], rst["uv_invalid"])
+    if name == "Zoo":
+        assert st.NormalsWrongMagnitude > 0
     assert n == 3 and np.isfinite(got).all()
     close = (np.abs(got - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2) + 1e-5).all(axis=2).mean()
     assert close > 0.985, f"{VIS_NAMES[vis]} on {name}: only {close:.4f} of pixels match"
