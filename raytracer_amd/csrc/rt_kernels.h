@@ -543,6 +543,57 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
     stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, cnt.nodes, cnt.prims);
 }
 
+// One lane per SHADOW RAY instead of per request ("1 thread per (hit, light, light-sample)").  A block pass takes
+// G = TB / R whole requests (R = lights x samples rays each); thread t traces ray t mod R of request t / R, so the R rays of a
+// request — same origin, R lights — sit in neighbouring lanes and walk the same top of the tree (with 64 lights a wave IS one
+// request: its node fetches hit the same cache lines), and no lane carries a request's running sums through 64 traversals.
+// The contributions meet in LDS and the request's first lane adds them in ray order, 0 + c0 + c1 + ...: the same additions in
+// the same order as k_shadow, so the same bits.  Not for Phong materials (their second ray per light folds two sums): the
+// host launches it only for scenes without them, and only when R <= TB.
+template <class C, bool LDS, bool EXACT = false>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<LDS, TB>(sc);
+    __shared__ float contrib[3][TB];
+    const uint32_t n = rd.sqcount[depth];
+    const uint32_t n_lights = sc.n_lights, R = rd.light_samples * n_lights;
+    const uint32_t G = (uint32_t)TB / R;                                          // whole requests per block pass (the host guarantees 1 <= R <= TB)
+    const uint32_t my_req = threadIdx.x / R, q = threadIdx.x - my_req * R;        // q = sample * n_lights + light: the order k_shadow walks
+    const uint32_t li = q % n_lights;
+    uint32_t rays = 0;
+    TravCount cnt = trav_count_zero();
+    float4* next_l = rd.st[(depth & 1) ^ 1][2];
+    for (uint32_t base = blockIdx.x * G; base < n; base += gridDim.x * G) {       // (block-uniform: every thread reaches both barriers)
+        const uint32_t p = base + my_req;
+        const bool have = my_req < G && p < n;
+        col3 c = mkc(0, 0, 0);
+        if (have) {
+            const float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p];
+            const f3 wp = mk3(h0.x, h0.y, h0.z), nrm = mk3(h0.w, h1.x, h1.y);
+            const RngKey key = path_key(rd, __float_as_uint(rd.sh[2][p].y));
+            const rt_light* l = sc.lights + li;
+            const ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, q);
+            rays++;
+            if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
+        }
+        contrib[0][threadIdx.x] = c.r; contrib[1][threadIdx.x] = c.g; contrib[2][threadIdx.x] = c.b;
+        __syncthreads();
+        if (have && q == 0) {
+            col3 sum = mkc(0, 0, 0);
+            for (uint32_t i = 0; i < R; i++) sum = sum + mkc(contrib[0][threadIdx.x + i], contrib[1][threadIdx.x + i], contrib[2][threadIdx.x + i]);
+            sum = over_samples<EXACT>(sum, (float)rd.light_samples);
+            const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
+            const col3 add = mkc(e1.z, e1.w, e2.x) * sum;
+            const uint32_t dst = __float_as_uint(e2.z), id = __float_as_uint(e2.y);
+            float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
+            float4 t = *tgt;
+            if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
+            *tgt = t;
+        }
+        __syncthreads();
+    }
+    stat_add3_block(rd.stats, ST_SHADOW_RAYS, ST_SH_NODES, ST_SH_PRIMS, rays, cnt.nodes, cnt.prims);
+}
 // Persistent-lane k_shadow (same reasoning as k_closest_persistent).  A request's rays are traced one after the other by its
 // lane, and an occluded ray ends at its first hit: with 64 lights the lane whose rays all reach their light sets the pace of the
 // wave 64 times per request.  Here a lane that has finished a ray accounts for it, draws the next one of its request (or writes
@@ -769,14 +820,18 @@ struct KernelSet {
     void (*shadow_lds_exact)(SceneDev, RenderDev, uint32_t);
     void (*closest_lds)(SceneDev, RenderDev, uint32_t);
     void (*shadow_lds)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_rays)(SceneDev, RenderDev, uint32_t);            // one lane per shadow ray (k_shadow_rays)
+    void (*shadow_rays_exact)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_rays_lds)(SceneDev, RenderDev, uint32_t);
+    void (*shadow_rays_lds_exact)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
     void (*trace_any_lds)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
                 k_closest_persistent<C, false>, k_shadow_persistent<C, false>, k_shadow<C, false, true>, k_shadow_persistent<C, false, true>, nullptr,
-                nullptr, nullptr, nullptr, nullptr};
-    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+                nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr};
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }
 

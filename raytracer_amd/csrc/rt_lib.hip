@@ -88,6 +88,8 @@ struct rt_scene {
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
     bool device_build = false;       // the tree was built by rt_lbvh.hip
+    int shadow_rays = -1;            // one lane per shadow ray (k_shadow_rays): -1 = the library's rule, 0/1 = RT_HIP_SHADOW_RAYS
+    bool has_phong = false;          // a Phong material somewhere: k_shadow_rays cannot fold its two sums
     int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
     uint32_t n_objects = 0, n_lights = 0;
@@ -117,7 +119,8 @@ void bind_scene_pointers(rt_scene* s) {
 // cap rt_scene_create admits (80 KB), never to one scene's need: a second scene cannot lower the first one's limit.
 constexpr size_t LDS_TREE_CAP = 80 * 1024;
 int allow_big_lds(const KernelSet* ks) {
-    const void* fns[5] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact};
+    const void* fns[7] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
+                          (const void*)ks->shadow_rays_lds, (const void*)ks->shadow_rays_lds_exact};
     for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
     return RT_OK;
 }
@@ -505,6 +508,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 1014 Msamples/s with
     // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
     { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
+    { const char* e = getenv("RT_HIP_SHADOW_RAYS"); s->shadow_rays = e ? (e[0] == '1') : -1; }
+    s->has_phong = (m_mats >> RT_MAT_PHONG) & 1u;
     { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && n_nodes * sizeof(Node) > (64u << 20)); }
     *out = s.release();
     return RT_OK;
@@ -538,7 +543,7 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     if (int rc = scratch_for_device(device)) return rc;
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
-    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->persistent = src->persistent;
+    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->persistent = src->persistent;
     s->n_objects = src->n_objects; s->n_lights = src->n_lights;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -848,6 +853,13 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     // wave: 100 k spheres + 64 lights 766 -> 728 ms per batch; with 2-4 rays per request the refill rounds cost more than they save.
     const bool shadow_persistent = s->persistent_shadow >= 0 ? s->persistent_shadow != 0 : (uint64_t)rd.light_samples * s->n_lights >= 32;
     const bool ex = r->exact_lights;
+    const uint64_t per_request = (uint64_t)rd.light_samples * s->n_lights;
+    const bool ray_lanes_ok = !s->has_phong && per_request >= 1 && per_request <= (uint64_t)(s->use_lds ? LDS_BLOCK_SHADOW : BLOCK) && (s->use_lds ? ks->shadow_rays_lds != nullptr : ks->shadow_rays != nullptr);
+    // Measured per shadow kernel and batch (RT_HIP_SHADOW_RAYS=0/1): Cornell (list, 2 rays per request) 53.4 -> 49.6 ms, the 5 M-triangle
+    // mesh 47.7 -> 42.8, Demo 2.20 -> 2.12; Night Spheres (tree in LDS) 67.3 -> 75.9 — two rays per request do not pay for loading the
+    // request twice and the two barriers — and 100 k spheres + 64 lights 570 (persistent request lanes) -> 768: a wave that IS one
+    // request waits for the longest of its 64 rays.  Hence: trees outside LDS, requests of fewer than 32 rays.
+    const bool ray_lanes = ray_lanes_ok && (s->shadow_rays >= 0 ? s->shadow_rays != 0 : (s->persistent_shadow < 0 && !s->use_lds && per_request < 32));
     { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
@@ -855,7 +867,9 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          else if (ray_lanes) hipLaunchKernelGGL(ex ? ks->shadow_rays_exact : ks->shadow_rays, dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
+          else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on
