@@ -128,6 +128,10 @@ extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsT
 // Traversal kernels come in two forms: TB = BLOCK reading the tree through the cache hierarchy, and (small all-sphere scenes)
 // TB = a larger workgroup that first copies the scene's LDS image and then never touches the vector cache for nodes or spheres.
 constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = 512;
+#ifndef RT_LDS_BLOCK_RAYS
+#define RT_LDS_BLOCK_RAYS 768
+#endif
+constexpr int LDS_BLOCK_RAYS = RT_LDS_BLOCK_RAYS;      // k_shadow_rays with the tree in LDS: 81 VGPRs let 6 waves/SIMD in, two blocks of 12 waves per CU
 template <bool LDS, int TB>
 RT_FN auto make_tree(const SceneDev& sc) {
     if constexpr (LDS) {
@@ -551,8 +555,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
 // the same order as k_shadow, so the same bits.  Not for Phong materials (their second ray per light folds two sums): the
 // host launches it only for scenes without them, and only when R <= TB.
 template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
-    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 6 : 1) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr int TB = LDS ? LDS_BLOCK_RAYS : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     __shared__ float contrib[3][TB];
     const uint32_t n = rd.sqcount[depth];

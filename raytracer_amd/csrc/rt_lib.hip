@@ -568,12 +568,13 @@ static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t block
 }
 static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * sizeof(int); }
 static inline size_t lds_tree_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
-static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) {
+static inline uint32_t lds_grid_for(const rt_scene* s, uint64_t work, int block, size_t lds_bytes) {
     uint64_t need = (work + block - 1) / block;
-    uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds_tree_bytes(s, block));
+    uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds_bytes);
     per_cu = std::min<uint64_t>(per_cu, 2048 / block);
     return (uint32_t)std::max<uint64_t>(1, std::min(need, (uint64_t)s->n_cu * per_cu));
 }
+static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) { return lds_grid_for(s, work, block, lds_tree_bytes(s, block)); }
 
 // -------------------------------------------------------------------------------------------------
 // Parity hooks
@@ -854,7 +855,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     const bool shadow_persistent = s->persistent_shadow >= 0 ? s->persistent_shadow != 0 : (uint64_t)rd.light_samples * s->n_lights >= 32;
     const bool ex = r->exact_lights;
     const uint64_t per_request = (uint64_t)rd.light_samples * s->n_lights;
-    const bool ray_lanes_ok = !s->has_phong && per_request >= 1 && per_request <= (uint64_t)(s->use_lds ? LDS_BLOCK_SHADOW : BLOCK) && (s->use_lds ? ks->shadow_rays_lds != nullptr : ks->shadow_rays != nullptr);
+    const bool ray_lanes_ok = !s->has_phong && per_request >= 1 && per_request <= (uint64_t)(s->use_lds ? LDS_BLOCK_RAYS : BLOCK) && (s->use_lds ? ks->shadow_rays_lds != nullptr : ks->shadow_rays != nullptr);
     // Measured per shadow kernel and batch (RT_HIP_SHADOW_RAYS=0/1): Cornell (list, 2 rays per request) 53.4 -> 49.6 ms, the 5 M-triangle
     // mesh 47.7 -> 42.8, Demo 2.20 -> 2.12; Night Spheres (tree in LDS) 67.3 -> 75.9 — two rays per request do not pay for loading the
     // request twice and the two barriers — and 100 k spheres + 64 lights 570 (persistent request lanes) -> 768: a wave that IS one
@@ -867,7 +868,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_tree_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_tree_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
           else if (ray_lanes) hipLaunchKernelGGL(ex ? ks->shadow_rays_exact : ks->shadow_rays, dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
