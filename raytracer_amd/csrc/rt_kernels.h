@@ -127,7 +127,10 @@ extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsT
 
 // Traversal kernels come in two forms: TB = BLOCK reading the tree through the cache hierarchy, and (small all-sphere scenes)
 // TB = a larger workgroup that first copies the scene's LDS image and then never touches the vector cache for nodes or spheres.
-constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = 512;
+#ifndef RT_LDS_BLOCK_SHADOW
+#define RT_LDS_BLOCK_SHADOW 1024
+#endif
+constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = RT_LDS_BLOCK_SHADOW;
 #ifndef RT_LDS_BLOCK_RAYS
 #define RT_LDS_BLOCK_RAYS 768
 #endif
