@@ -303,7 +303,7 @@ template <class C, bool VIS = false>
 __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
-    unsigned long long sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0, n_warn = 0, uv_warn = 0;
+    uint32_t sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0, n_warn = 0, uv_warn = 0;      // per thread: far below 2^32 (a thread shades a few thousand paths per launch)
     __shared__ uint32_t wcnt[2][SHADE_ITEMS][BLOCK / 64];
     __shared__ uint32_t bases[2];
     constexpr uint32_t TILE = SHADE_ITEMS * BLOCK;
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     {   // (RenderJob.cs:458: a miss at depth d ends a path of maxDepthReached d-1, the bounce limit one of depth d; a primary miss is not counted)
         const int slot[8] = {ST_SKY, ST_LIMIT, ST_SCATTER, ST_SAMPLES, ST_DEPTH0 + (int)min(depth > 0 ? depth - 1 : 0u, (uint32_t)RT_DEPTH_HIST_SIZE - 1),
                              ST_DEPTH0 + (int)min(depth, (uint32_t)RT_DEPTH_HIST_SIZE - 1), ST_NORMAL_WARN, ST_UV_WARN};
-        const unsigned long long v[8] = {sky, limit, scat, samples, depth > 0 ? hist_miss : 0ull, limit, n_warn, uv_warn};
+        const unsigned long long v[8] = {sky, limit, scat, samples, depth > 0 ? hist_miss : 0u, limit, n_warn, uv_warn};
         stat_add_block<8>(rd.stats, slot, v);
     }
 }
