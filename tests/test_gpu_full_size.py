@@ -50,18 +50,19 @@ def _ray_parity(sc, flat, dev, orc, n_closest, n_list, seed, n_any=120_000):
 
 def _render_vs_culled_oracle(sc, dev_flat, orc, opt, min_close, monkeypatch):
     """An image at a size the oracle can only afford with culled shadow rays, in exact-lights mode (every shadow ray bit-identical),
-    through the shadow kernel the host would pick AND through the other one (RT_HIP_PERSISTENT_SHADOW forced off / on)."""
+    through each of the three shadow kernels (RT_HIP_PERSISTENT_SHADOW forced off / on, RT_HIP_SHADOW_RAYS forced on)."""
     orc.set_culled_any(True)
     ref, rst = orc.render(opt, threads=16)
     orc.set_culled_any(False)
-    for forced in ("0", "1"):
-        monkeypatch.setenv("RT_HIP_PERSISTENT_SHADOW", forced)
+    # every shadow kernel the library has for this scene: request lanes (k_shadow), persistent request lanes, ray lanes (k_shadow_rays)
+    for var, forced, what in (("RT_HIP_PERSISTENT_SHADOW", "0", "k_shadow"), ("RT_HIP_PERSISTENT_SHADOW", "1", "k_shadow_persistent"), ("RT_HIP_SHADOW_RAYS", "1", "k_shadow_rays")):
+        monkeypatch.setenv(var, forced)
         dev = rt.DeviceScene(dev_flat)
-        monkeypatch.delenv("RT_HIP_PERSISTENT_SHADOW")
+        monkeypatch.delenv(var)
         job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); st = job.RenderStats; job.Dispose(); dev.Dispose()
         close = _image_close(got, ref)
-        assert close >= min_close, f"persistent shadow kernel {forced}: only {close:.5f} of pixels match"
-        assert (st.RayCount, st.ShadowRays) == (rst["ray_count"], rst["shadow_rays"])
+        assert close >= min_close, f"{what}: only {close:.5f} of pixels match"
+        assert (st.RayCount, st.ShadowRays) == (rst["ray_count"], rst["shadow_rays"]), what
 
 
 def _image_close(got, ref):
@@ -190,6 +191,27 @@ def test_config5_hundred_thousand_spheres_64_lights(monkeypatch):
     dev.Dispose()
     _render_vs_culled_oracle(sc, flat, orc, RenderOptions(RenderWidth=320, RenderHeight=180, Passes=2, MaxBounceDepth=10, LightSampleCountHint=1, Seed=0xC5,
                                                           ExactLightSampling=True, ExactOcclusion=True), 0.999, monkeypatch)
+
+
+@pytest.mark.parametrize("builder", ["device", "ploc"])
+def test_config5_device_built_trees_give_the_host_trees_hits(builder, monkeypatch):
+    """100 000 spheres: the trees built on the GPU (rt_lbvh.hip, rt_ploc.hip) against the host's SAH tree — 200 k closest hits bit for
+    bit (K included: the leaf boxes and intersectors are the same, only the order of the tests differs) and 200 k any-hit answers."""
+    sc = bs.ManySpheresManyLights(); flat = flatten_scene(sc)
+    host = rt.DeviceScene(flat)
+    monkeypatch.setenv("RT_HIP_BVH", builder)
+    dev = rt.DeviceScene(flat)
+    monkeypatch.delenv("RT_HIP_BVH")
+    assert dev.Info()["built_on_device"] and not host.Info()["built_on_device"] and dev.Info()["n_nodes"] == host.Info()["n_nodes"]
+    rs = np.random.default_rng(55)
+    o1, d1 = helpers.camera_rays(sc, 64, 64, 100_000, rs)
+    o2, d2 = helpers.secondary_rays(flat, 100_000, rs)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = dev.TraceClosest(o, d, 0.001, np.inf, seed=3), host.TraceClosest(o, d, 0.001, np.inf, seed=3)
+    helpers.assert_closest_parity(a, b)
+    kmin = np.full(len(o), 0.01, np.float32); kmax = rs.uniform(0.5, 60.0, len(o)).astype(np.float32)
+    assert np.array_equal(dev.TraceAny(o, d, kmin, kmax), host.TraceAny(o, d, kmin, kmax))
+    dev.Dispose(); host.Dispose()
 
 
 def test_check1_two_million_rays_night_spheres():
