@@ -49,6 +49,7 @@ struct RenderDev {
     uint64_t seed;
     float k_min, k_max;
     uint32_t max_depth, light_samples;
+    uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
@@ -90,9 +91,27 @@ RT_FN void stat_add3_block(unsigned long long* stats, int s0, int s1, int s2, ui
     const int slot[3] = {s0, s1, s2}; const unsigned long long v[3] = {v0, v1, v2};
     stat_add_block<3>(stats, slot, v);
 }
-RT_FN void stat_add_closest(unsigned long long* stats, uint32_t rays, const TravCount& c) {
-    const int slot[5] = {ST_RAYS, ST_NODES, ST_PRIMS, ST_BOX_MISS, ST_PRIM_HIT}; const unsigned long long v[5] = {rays, c.nodes, c.prims, c.box_miss, c.prim_hit};
-    stat_add_block<5>(stats, slot, v);
+// (+ the paths a closest-hit kernel finished itself because they hit nothing: finish_miss below)
+RT_FN void stat_add_closest(unsigned long long* stats, uint32_t rays, const TravCount& c, uint32_t sky, uint32_t depth) {
+    const int slot[8] = {ST_RAYS, ST_NODES, ST_PRIMS, ST_BOX_MISS, ST_PRIM_HIT, ST_SKY, ST_SAMPLES, ST_DEPTH0 + (int)min(depth > 0 ? depth - 1 : 0u, (uint32_t)RT_DEPTH_HIST_SIZE - 1)};
+    const unsigned long long v[8] = {rays, c.nodes, c.prims, c.box_miss, c.prim_hit, sky, sky, depth > 0 ? sky : 0u};
+    stat_add_block<8>(stats, slot, v);
+}
+
+// A path whose ray hit nothing ends here (RenderJob.cs:444-450: the sky's colour times the throughput, on top of what the path has
+// collected), inside the closest-hit kernel that found it out: the kernel holds the ray and two thirds of the throughput already,
+// reads the rest of the state (24 B) and writes the path's radiance — and k_shade never loads the 56 B of a path that missed
+// (a third of all paths it used to process on Night Spheres: k_shade 56.4 -> 49.9, k_closest 47.7 -> 49.7 ms per step).  Only for
+// trees in LDS: where the tree is read through the caches the extra registers cost the traversal more than k_shade saves
+// (Cornell k_closest 23.8 -> 30.2 for -5.0 in k_shade, 5 M triangles 84.4 -> 89.6 for -1.8).  Not in debug-visualisation
+// renders, whose misses have their own colours (k_shade<CfgAll, true> keeps them).  g1w = the path's second state word (dir.y, dir.z, T.r, T.g).
+RT_FN void finish_miss(const SceneDev& sc, const RenderDev& rd, uint32_t depth, uint32_t j, f3 dir, float4 g1w) {
+    const float4 g2w = rd.st[depth & 1][2][j];
+    const uint32_t id = rd.ids[depth & 1][j].x;
+    const col3 T = mkc(g1w.z, g1w.w, g2w.x);
+    col3 L = mkc(g2w.y, g2w.z, g2w.w);
+    L = L + (T * sky_colour(sc, dir));
+    rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
 }
 
 RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
@@ -156,7 +175,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.qcount[depth];
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
-    uint32_t rays = 0;
+    uint32_t rays = 0, sky = 0;
+    const bool finish = LDS && rd.misses_end_in_closest;       // a ray that hits nothing ends its path here (finish_miss)
     TravCount cnt = trav_count_zero();
     for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
         float4 a = g0[j], b = g1[j];
@@ -167,8 +187,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(Sce
         rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
         rays++;
+        if (c.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, j, r.d, b); sky++; }
     }
-    stat_add_closest(rd.stats, rays, cnt);
+    stat_add_closest(rd.stats, rays, cnt, sky, depth);
 }
 
 // Persistent-lane closest hit.  In scenes where the cost of a ray has a heavy tail (a bounce ray skimming a 5 M-triangle terrain
@@ -203,7 +224,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     const uint32_t end = min(n, next + per_wave);
     const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
     uint32_t my_j = 0;
-    uint32_t rays = 0;
+    uint32_t rays = 0, sky = 0;
+    const bool finish = LDS && rd.misses_end_in_closest;       // a ray that hits nothing ends its path here (finish_miss)
     TravCount cnt = trav_count_zero();
     bool active = false;                 // this lane holds a ray (possibly finished and waiting for its store)
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
@@ -229,6 +251,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
                 if (best.obj != RT_NO_HIT && !((best.k >= kMin) && (best.k <= kMax))) best.obj = RT_NO_HIT;
                 rd.hit[my_j] = make_float2(best.k, __uint_as_float(best.obj));
+                if (best.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, my_j, r.d, g1[my_j]); sky++; }
                 active = false;
             }
             const uint32_t j = next + (uint32_t)__popcll(idle & lt_mask);
@@ -268,7 +291,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
             if (n_busy < REFILL_BELOW && next < end && 64 - n_busy >= REFILL_MIN_TAKERS) break;
         }
     }
-    stat_add_closest(rd.stats, rays, cnt);
+    stat_add_closest(rd.stats, rays, cnt, sky, depth);
 }
 
 // Output positions.  A same-address returning atomic is serviced about every 10 ns chip-wide, so a reservation per wave
@@ -311,7 +334,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool can_survive = depth < rd.max_depth;
     for (uint32_t tile = blockIdx.x * TILE; tile < n; tile += gridDim.x * TILE) {     // uniform per block
-      uint32_t m_surv = 0, m_shad = 0;
+      uint32_t m_surv = 0, m_shad = 0, m_hit = 0;
 #pragma unroll
       for (int item = 0; item < SHADE_ITEMS; item++) {
           const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
@@ -326,7 +349,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
           const bool surv = hit && can_survive;
           unsigned long long bs = __ballot(surv), bl = __ballot(lit);
           if (lane == 0) { wcnt[0][item][wave] = (uint32_t)__popcll(bs); wcnt[1][item][wave] = (uint32_t)__popcll(bl); }
-          m_surv |= (surv ? 1u : 0u) << item; m_shad |= (lit ? 1u : 0u) << item;
+          m_surv |= (surv ? 1u : 0u) << item; m_shad |= (lit ? 1u : 0u) << item; m_hit |= (hit ? 1u : 0u) << item;
       }
       __syncthreads();
       if (threadIdx.x < 2) {
@@ -349,7 +372,9 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
         }
         p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
         p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
-        if (j < n) {
+        // (a path whose ray hit nothing was finished by the closest-hit kernel — finish_miss — and its state is not even loaded here;
+        //  debug visualisations colour their misses themselves)
+        if (j < n && (VIS || !rd.misses_end_in_closest || ((m_hit >> item) & 1u))) {
             const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j]; const uint2 a3 = rd.ids[cur][j];
             const float2 hk = rd.hit[j];
             Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
