@@ -49,6 +49,7 @@ struct RenderDev {
     uint64_t seed;
     float k_min, k_max;
     uint32_t max_depth, light_samples;
+    uint32_t compact_requests;        // shadow requests of surviving paths are 16 B and point at the survivor's state (req_head): no Phong material, no debug visualisation
     uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
@@ -112,6 +113,42 @@ RT_FN void finish_miss(const SceneDev& sc, const RenderDev& rd, uint32_t depth, 
     col3 L = mkc(g2w.y, g2w.z, g2w.w);
     L = L + (T * sky_colour(sc, dir));
     rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
+}
+
+// A shadow request (what k_shade leaves for the shadow kernels about a hit that samples the lights), in one of two layouts:
+//   full (48 B):    sh[0] = (point.xyz, normal.x)  sh[1] = (normal.yz, W.rg)  sh[2] = (W.b, path id, survivor position or RT_NO_HIT, object)
+//   compact (16 B): sh[0] = (normal.xyz, survivor position).  When the path survives the bounce its next state already holds the
+//                   rest: the new ray starts at the hit point, the new throughput T * a IS the light weight W of the Standard and
+//                   refractive materials (StandardMaterial.cs:74-80: future and light sum share the albedo factor), and the path id
+//                   sits beside it.  k_shade then writes 16 instead of 48 B per request (a fifth of all it writes on Night Spheres).
+// Compact needs every lit hit to survive (depth < max depth: launch-uniform), W == T * a (no Phong material in the scene) and no
+// debug visualisation (EstimatedLight weighs with 1): rd.compact_requests says the last two.
+RT_FN bool requests_are_compact(const RenderDev& rd, uint32_t depth) { return rd.compact_requests && depth < rd.max_depth; }
+struct ReqHead { f3 wp, nrm; uint32_t id; float obj_bits; };
+RT_FN ReqHead req_head(const RenderDev& rd, uint32_t depth, uint32_t p, bool compact) {
+    ReqHead q;
+    if (compact) {
+        const float4 h = rd.sh[0][p];
+        const uint32_t dst = __float_as_uint(h.w);
+        const float4 s0 = rd.st[(depth & 1) ^ 1][0][dst];
+        q.wp = mk3(s0.x, s0.y, s0.z); q.nrm = mk3(h.x, h.y, h.z); q.id = rd.ids[(depth & 1) ^ 1][dst].x; q.obj_bits = 0.0f;
+    } else {
+        const float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
+        q.wp = mk3(h0.x, h0.y, h0.z); q.nrm = mk3(h0.w, h1.x, h1.y); q.id = __float_as_uint(h2.y); q.obj_bits = h2.w;
+    }
+    return q;
+}
+// the rest of a request, read when its rays are done: the weight of the light sum, where the light goes (the survivor's state, or
+// the finished path's radiance), the path id
+RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compact, col3& W, uint32_t& dst, uint32_t& id) {
+    if (compact) {
+        dst = __float_as_uint(rd.sh[0][p].w); id = 0;
+        const float4 e1 = rd.st[(depth & 1) ^ 1][1][dst], e2 = rd.st[(depth & 1) ^ 1][2][dst];
+        W = mkc(e1.z, e1.w, e2.x);
+    } else {
+        const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
+        W = mkc(e1.z, e1.w, e2.x); dst = __float_as_uint(e2.z); id = __float_as_uint(e2.y);
+    }
 }
 
 RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
@@ -477,7 +514,8 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                         default: L = bounce_depth_colour((int)depth, rd.max_depth); break;            // BounceDepth: used if the path ends here (bounce limit)
                     }
                 }
-                if (shadow) {
+                if (shadow && !VIS && requests_are_compact(rd, depth)) rd.sh[0][p1] = make_float4(h.n.x, h.n.y, h.n.z, __uint_as_float(p0));
+                else if (shadow) {
                     rd.sh[0][p1] = make_float4(h.wp.x, h.wp.y, h.wp.z, h.n.x);
                     rd.sh[1][p1] = make_float4(h.n.y, h.n.z, W.r, W.g);
                     rd.sh[2][p1] = make_float4(W.b, __uint_as_float(id), __uint_as_float(survive ? p0 : RT_NO_HIT), __uint_as_float(c.obj));
@@ -520,22 +558,23 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
+    const bool compact = requests_are_compact(rd, depth);
     uint32_t rays = 0;                                // per thread: at most a few thousand requests x rays x nodes
     TravCount cnt = trav_count_zero();
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     for (uint32_t p = blockIdx.x * TB + threadIdx.x; p < n; p += gridDim.x * TB) {
-        float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
-        f3 wp = mk3(h0.x, h0.y, h0.z);
-        f3 nrm = mk3(h0.w, h1.x, h1.y);
-        const uint32_t id = __float_as_uint(h2.y);                  // (the weight W and the destination are re-read after the traversals: 4 registers fewer across them)
-        RngKey key = path_key(rd, id);
+        const ReqHead rq = req_head(rd, depth, p, compact);
+        const f3 wp = rq.wp, nrm = rq.nrm;                          // (the weight W and the destination are read after the traversals: 4 registers fewer across them)
+        RngKey key = path_key(rd, rq.id);
         const rt_material* m = nullptr;
         bool phong = false;
         f3 in = mk3(0, 0, 0);
         if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
-            m = sc.materials + sc.obj_material[__float_as_uint(h2.w)];
-            phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;      // EstimatedLight is the plain light sum whatever the material (RenderJob.cs:234-250)
-            if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+            if (!compact) {                                         // (compact requests: no Phong material in the scene)
+                m = sc.materials + sc.obj_material[__float_as_uint(rq.obj_bits)];
+                phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;      // EstimatedLight is the plain light sum whatever the material (RenderJob.cs:234-250)
+                if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+            }
         }
         col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0);
         for (uint32_t s = 0; s < rd.light_samples; s++) {
@@ -561,9 +600,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
         }
         const float S = (float)rd.light_samples;
         sum = over_samples<EXACT>(sum, S);
-        const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
-        const col3 W = mkc(e1.z, e1.w, e2.x);
-        const uint32_t dst = __float_as_uint(e2.z);
+        col3 W; uint32_t dst, id;
+        req_tail(rd, depth, p, compact, W, dst, id);
         col3 add;
         if (!phong) add = W * sum;
         else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
@@ -589,6 +627,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
     __shared__ float contrib[3][TB];
     const uint32_t n = rd.sqcount[depth];
     const uint32_t n_lights = sc.n_lights, R = rd.light_samples * n_lights;
+    const bool compact = requests_are_compact(rd, depth);
     const uint32_t G = (uint32_t)TB / R;                                          // whole requests per block pass (the host guarantees 1 <= R <= TB)
     const uint32_t my_req = threadIdx.x / R, q = threadIdx.x - my_req * R;        // q = sample * n_lights + light: the order k_shadow walks
     const uint32_t li = q % n_lights;
@@ -600,9 +639,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
         const bool have = my_req < G && p < n;
         col3 c = mkc(0, 0, 0);
         if (have) {
-            const float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p];
-            const f3 wp = mk3(h0.x, h0.y, h0.z), nrm = mk3(h0.w, h1.x, h1.y);
-            const RngKey key = path_key(rd, __float_as_uint(rd.sh[2][p].y));
+            const ReqHead rq = req_head(rd, depth, p, compact);
+            const f3 wp = rq.wp, nrm = rq.nrm;
+            const RngKey key = path_key(rd, rq.id);
             const rt_light* l = sc.lights + li;
             const ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, q);
             rays++;
@@ -614,9 +653,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
             col3 sum = mkc(0, 0, 0);
             for (uint32_t i = 0; i < R; i++) sum = sum + mkc(contrib[0][threadIdx.x + i], contrib[1][threadIdx.x + i], contrib[2][threadIdx.x + i]);
             sum = over_samples<EXACT>(sum, (float)rd.light_samples);
-            const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
-            const col3 add = mkc(e1.z, e1.w, e2.x) * sum;
-            const uint32_t dst = __float_as_uint(e2.z), id = __float_as_uint(e2.y);
+            col3 W; uint32_t dst, id;
+            req_tail(rd, depth, p, compact, W, dst, id);
+            const col3 add = W * sum;
             float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
             float4 t = *tgt;
             if (dst != RT_NO_HIT) { t.y += add.r; t.z += add.g; t.w += add.b; } else { t.x += add.r; t.y += add.g; t.z += add.b; }
@@ -640,6 +679,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     const auto tree = make_tree<LDS, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
     const uint32_t n_lights = sc.n_lights, per_request = rd.light_samples * n_lights;
+    const bool compact = requests_are_compact(rd, depth);
     // every wave owns a contiguous run of the request queue (as in k_closest_persistent)
     const uint32_t n_waves = gridDim.x * (TB / 64), wave_id = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
     const uint32_t per_wave = (n + n_waves - 1) / n_waves;
@@ -688,9 +728,8 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                 if (q == per_request) {                                         // ---- the request is complete: add its light to the path
                     const float S = (float)rd.light_samples;
                     sum = over_samples<EXACT>(sum, S);
-                    const float4 e1 = rd.sh[1][p], e2 = rd.sh[2][p];
-                    const col3 W = mkc(e1.z, e1.w, e2.x);
-                    const uint32_t dst = __float_as_uint(e2.z), id = __float_as_uint(e2.y);
+                    col3 W; uint32_t dst, id;
+                    req_tail(rd, depth, p, compact, W, dst, id);
                     col3 add;
                     if (!phong) add = W * sum;
                     else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
@@ -704,13 +743,16 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
             const uint32_t p_new = next + (uint32_t)__popcll(__ballot(!have) & lt_mask);      // (the idle lanes are the active ones here)
             if (!have && p_new < end) {                                         // ---- next request
                 p = p_new; fetched = true;
-                float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
-                wp = mk3(h0.x, h0.y, h0.z); nrm = mk3(h0.w, h1.x, h1.y);
-                key = path_key(rd, __float_as_uint(h2.y));
+                const ReqHead rq = req_head(rd, depth, p, compact);
+                wp = rq.wp; nrm = rq.nrm;
+                key = path_key(rd, rq.id);
                 if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
-                    m = sc.materials + sc.obj_material[__float_as_uint(h2.w)];
-                    phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;
-                    if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+                    phong = false;
+                    if (!compact) {                                             // (compact requests: no Phong material in the scene)
+                        m = sc.materials + sc.obj_material[__float_as_uint(rq.obj_bits)];
+                        phong = m->type == RT_MAT_PHONG && rd.vis != RT_VIS_ESTIMATED_LIGHT;
+                        if (phong) { float4 h3 = rd.sh[3][p]; in = mk3(h3.x, h3.y, h3.z); }
+                    }
                 }
                 sum = mkc(0, 0, 0); spec_sum = mkc(0, 0, 0);
                 q = 0; li = 0; second = false; have = true;

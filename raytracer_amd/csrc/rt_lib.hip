@@ -775,6 +775,7 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
         rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
         rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
+        rd.compact_requests = (!s->has_phong && o->debug_visualisation == RT_VIS_NONE && !getenv("RT_HIP_FULL_REQUESTS")) ? 1u : 0u;
         rd.misses_end_in_closest = (s->use_lds && o->debug_visualisation == RT_VIS_NONE) ? 1u : 0u;
         rd.any_cap = r->exact_occlusion ? INFINITY : RT_ANY_GROWTH_CAP;
         rd.vis = o->debug_visualisation;
