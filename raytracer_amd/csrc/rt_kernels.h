@@ -124,25 +124,25 @@ RT_FN void finish_miss(const SceneDev& sc, const RenderDev& rd, uint32_t depth, 
 // Compact needs every lit hit to survive (depth < max depth: launch-uniform), W == T * a (no Phong material in the scene) and no
 // debug visualisation (EstimatedLight weighs with 1): rd.compact_requests says the last two.
 RT_FN bool requests_are_compact(const RenderDev& rd, uint32_t depth) { return rd.compact_requests && depth < rd.max_depth; }
-struct ReqHead { f3 wp, nrm; uint32_t id; float obj_bits; };
+struct ReqHead { f3 wp, nrm; uint32_t id, dst; float obj_bits; };      // dst: compact requests only (kept across the traversals: one register instead of a reload)
 RT_FN ReqHead req_head(const RenderDev& rd, uint32_t depth, uint32_t p, bool compact) {
     ReqHead q;
     if (compact) {
         const float4 h = rd.sh[0][p];
         const uint32_t dst = __float_as_uint(h.w);
         const float4 s0 = rd.st[(depth & 1) ^ 1][0][dst];
-        q.wp = mk3(s0.x, s0.y, s0.z); q.nrm = mk3(h.x, h.y, h.z); q.id = rd.ids[(depth & 1) ^ 1][dst].x; q.obj_bits = 0.0f;
+        q.wp = mk3(s0.x, s0.y, s0.z); q.nrm = mk3(h.x, h.y, h.z); q.id = rd.ids[(depth & 1) ^ 1][dst].x; q.dst = dst; q.obj_bits = 0.0f;
     } else {
         const float4 h0 = rd.sh[0][p], h1 = rd.sh[1][p], h2 = rd.sh[2][p];
-        q.wp = mk3(h0.x, h0.y, h0.z); q.nrm = mk3(h0.w, h1.x, h1.y); q.id = __float_as_uint(h2.y); q.obj_bits = h2.w;
+        q.wp = mk3(h0.x, h0.y, h0.z); q.nrm = mk3(h0.w, h1.x, h1.y); q.id = __float_as_uint(h2.y); q.dst = 0; q.obj_bits = h2.w;
     }
     return q;
 }
 // the rest of a request, read when its rays are done: the weight of the light sum, where the light goes (the survivor's state, or
 // the finished path's radiance), the path id
-RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compact, col3& W, uint32_t& dst, uint32_t& id) {
+RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compact, uint32_t head_dst, col3& W, uint32_t& dst, uint32_t& id) {
     if (compact) {
-        dst = __float_as_uint(rd.sh[0][p].w); id = 0;
+        dst = head_dst; id = 0;
         const float4 e1 = rd.st[(depth & 1) ^ 1][1][dst], e2 = rd.st[(depth & 1) ^ 1][2][dst];
         W = mkc(e1.z, e1.w, e2.x);
     } else {
@@ -564,6 +564,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     for (uint32_t p = blockIdx.x * TB + threadIdx.x; p < n; p += gridDim.x * TB) {
         const ReqHead rq = req_head(rd, depth, p, compact);
+        const uint32_t rq_dst = rq.dst;
         const f3 wp = rq.wp, nrm = rq.nrm;                          // (the weight W and the destination are read after the traversals: 4 registers fewer across them)
         RngKey key = path_key(rd, rq.id);
         const rt_material* m = nullptr;
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
         const float S = (float)rd.light_samples;
         sum = over_samples<EXACT>(sum, S);
         col3 W; uint32_t dst, id;
-        req_tail(rd, depth, p, compact, W, dst, id);
+        req_tail(rd, depth, p, compact, rq_dst, W, dst, id);
         col3 add;
         if (!phong) add = W * sum;
         else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
@@ -638,8 +639,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
         const uint32_t p = base + my_req;
         const bool have = my_req < G && p < n;
         col3 c = mkc(0, 0, 0);
+        uint32_t rq_dst = 0;
         if (have) {
             const ReqHead rq = req_head(rd, depth, p, compact);
+            rq_dst = rq.dst;
             const f3 wp = rq.wp, nrm = rq.nrm;
             const RngKey key = path_key(rd, rq.id);
             const rt_light* l = sc.lights + li;
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
             for (uint32_t i = 0; i < R; i++) sum = sum + mkc(contrib[0][threadIdx.x + i], contrib[1][threadIdx.x + i], contrib[2][threadIdx.x + i]);
             sum = over_samples<EXACT>(sum, (float)rd.light_samples);
             col3 W; uint32_t dst, id;
-            req_tail(rd, depth, p, compact, W, dst, id);
+            req_tail(rd, depth, p, compact, rq_dst, W, dst, id);
             const col3 add = W * sum;
             float4* tgt = dst != RT_NO_HIT ? next_l + dst : rd.out + id;
             float4 t = *tgt;
@@ -688,7 +691,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
     float4* next_l = rd.st[(depth & 1) ^ 1][2];
     uint32_t rays = 0, nodes = 0, prims = 0;
-    uint32_t p = 0, q = 0, li = 0;      // q: index of the request's ray in flight, li = q mod n_lights
+    uint32_t p = 0, q = 0, li = 0, rq_dst = 0;      // q: index of the request's ray in flight, li = q mod n_lights
     bool have = false, flying = false, occluded = false, second = false;       // second: the Phong material's unattenuated ray of the same light
     f3 wp = mk3(0, 0, 0), nrm = mk3(0, 0, 1), in = mk3(0, 0, 0);
     RngKey key = path_key(rd, 0);
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                     const float S = (float)rd.light_samples;
                     sum = over_samples<EXACT>(sum, S);
                     col3 W; uint32_t dst, id;
-                    req_tail(rd, depth, p, compact, W, dst, id);
+                    req_tail(rd, depth, p, compact, rq_dst, W, dst, id);
                     col3 add;
                     if (!phong) add = W * sum;
                     else { spec_sum = over_samples<EXACT>(spec_sum, S); add = W * ((sum * mkc(m->f[3], m->f[4], m->f[5])) + (spec_sum * mkc(m->f[0], m->f[1], m->f[2]))); }
@@ -744,6 +747,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
             if (!have && p_new < end) {                                         // ---- next request
                 p = p_new; fetched = true;
                 const ReqHead rq = req_head(rd, depth, p, compact);
+                rq_dst = rq.dst;
                 wp = rq.wp; nrm = rq.nrm;
                 key = path_key(rd, rq.id);
                 if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {
