@@ -288,8 +288,8 @@ typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61, same
                                                at distance D errs by ~1e-3 D, so from a ground point 10 000 units out a "hit" can lie 10 units
                                                outside the sphere's box, and the box tests of such a ray must let the whole scene through.
                                                Without the flag the boxes of a shadow ray grow by at most half the smallest round radius
-                                               (exact up to a reach of ~1 100 smallest radii); only pixels at the horizon of an unbounded
-                                               plane can differ, and a dense scene renders up to 20x faster.  rt_trace_any is always exact.
+                                               (exact up to a reach of ~1 100 smallest radii); only pixels whose shadow rays start farther than that
+                                               from the objects can differ (a ground plane seen towards the horizon), and a dense scene renders up to 20x faster.  rt_trace_any is always exact.
                                                RT_HIP_EXACT_OCCLUSION=1 sets it for every render. */
 
 typedef struct rt_render_opts {
