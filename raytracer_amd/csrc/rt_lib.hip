@@ -419,12 +419,30 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const char* e = getenv("RT_HIP_LIST");
         const size_t list_max = e ? (size_t)std::max(0, atoi(e)) : 16;
         if (!boxes.empty() && boxes.size() <= list_max) {
+            // Order: objects inside the scene before the ones that bound it.  Any-hit stops at the first occluder, and what occludes
+            // is what stands in the room, not its walls (the Cornell box lists its five walls first); closest hit asks everybody
+            // anyway and decides ties by object index, so the order changes no result.  "Bounds it" = how many faces of the object's
+            // box lie on the faces of the box around everything (stable sort by that count).
+            std::vector<size_t> ord(boxes.size());
+            {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (const rtbvh::Box& b : boxes) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.mn[a]); hi[a] = std::max(hi[a], b.mx[a]); }
+                std::vector<int> on_hull(boxes.size(), 0);
+                for (size_t k = 0; k < boxes.size(); k++)
+                    for (int a = 0; a < 3; a++) {
+                        const float tol = 2e-3f * std::max(hi[a] - lo[a], 1e-30f);
+                        on_hull[k] += (boxes[k].mn[a] - lo[a] <= tol) + (hi[a] - boxes[k].mx[a] <= tol);
+                    }
+                for (size_t k = 0; k < ord.size(); k++) ord[k] = k;
+                const char* o = getenv("RT_HIP_LIST_ORDER");
+                if (!(o && !strcmp(o, "scene"))) std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return on_hull[x] < on_hull[y]; });
+            }
             std::vector<Node> ln((boxes.size() + 1) / 2);
             for (size_t i = 0; i < ln.size(); i++) {
                 rtbvh::HostNode h; std::memset(&h, 0, sizeof(h));
                 for (int side = 0; side < 2; side++) {
-                    const size_t k = 2 * i + side;
-                    const bool have = k < boxes.size();
+                    const bool have = 2 * i + side < boxes.size();
+                    const size_t k = have ? ord[2 * i + side] : 0;
                     for (int a = 0; a < 3; a++) { h.q[2 * a + side] = have ? boxes[k].mn[a] : INFINITY; h.q[6 + 2 * a + side] = have ? boxes[k].mx[a] : -INFINITY; }
                     (side ? h.childB : h.childA) = have ? ~(int32_t)box_obj[k] : rtbvh::CHILD_EMPTY;
                 }
