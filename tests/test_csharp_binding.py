@@ -204,3 +204,31 @@ def test_backend_publishes_every_reference_stat_and_orders_destruction():
     assert BACKEND.index("rt_render_destroy(hRender)") < BACKEND.index("rt_scene_destroy(hScene)")
     assert "interface IRenderBackend" in BACKEND and "class HipRenderBackend : IRenderBackend" in BACKEND
     assert "MaxPassesPerCall = PassesPerCall" in BACKEND
+
+
+def test_console_runner_uses_names_that_exist():
+    """csharp/Console/Program.cs: every RenderOptions property it sets, every RenderStats field it prints and every
+    method it calls exists — in the backend source for what this port adds, in the mounted reference for the rest (that half skips
+    on the GPU box, where /root/reference does not exist)."""
+    src = open(os.path.join(ROOT, "csharp", "Console", "Program.cs")).read()
+    ours = ("Backend", "Devices", "ExactLightSampling", "ExactOcclusion")
+    for name in ours:
+        assert re.search(r"\b" + name + r"\s*=", src), name
+        assert name in BACKEND, f"{name} is not described by HipRenderBackend.cs"
+    assert "RenderBackend" in BACKEND and "enum RenderBackend { Cpu = 0, Hip = 1 }" in BACKEND
+    ref = "/root/reference/Ararem.RayTracer.Core"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not mounted")
+    options = open(os.path.join(ref, "RenderOptions.cs")).read()
+    for name in re.findall(r"^\t{5}(\w+)\s+=", src, flags=re.M):
+        if name not in ours:
+            assert re.search(r"public \S+ " + name + r"\b", options), f"RenderOptions has no property {name}"
+    stats = open(os.path.join(ref, "RenderStats.cs")).read()
+    for name in set(re.findall(r"\b(?:st|done)\.(\w+)", src)):
+        assert re.search(r"\b" + name + r"\b", stats), f"RenderStats has no {name}"
+    job = open(os.path.join(ref, "RenderJob.cs")).read()
+    for name in ("StartOrGetRenderAsync", "RenderStats", "Image"):
+        assert re.search(r"public .*\b" + name + r"\b", job), name
+    assert "public static IEnumerable<Scene> GetAll()" in open("/root/reference/Ararem.RayTracer.Impl/Builtin/BuiltinScenes.cs").read()
+    validator = open(os.path.join(ref, "Debugging", "GraphicsValidator.cs")).read()
+    assert "public static readonly ConcurrentDictionary<GraphicsErrorType, ConcurrentDictionary<object, ulong>> Errors" in validator
