@@ -15,7 +15,7 @@ REF = "/root/reference"
 SLACK = 3
 SCAN = ["oracle/oracle.cpp", "include/rt_hip.h", "raytracer_amd/csrc/rt_device.h", "raytracer_amd/csrc/rt_kernels.h", "raytracer_amd/csrc/rt_lib.hip",
         "raytracer_amd/csrc/rt_bvh.h", "raytracer_amd/csrc/rt_bvh.cpp", "raytracer_amd/csrc/rt_lbvh.hip", "csharp/HipRenderBackend.cs",
-        "csharp/Impl/DeviceFlatteners.cs", "csharp/Impl/DistanceAttenuation.cs", "csharp/Impl/Triangle.cs", "raytracer_amd/render_job.py",
+        "csharp/Impl/DeviceFlatteners.cs", "csharp/Impl/DistanceAttenuation.cs", "csharp/Impl/Triangle.cs", "csharp/Console/Program.cs", "raytracer_amd/render_job.py",
         "raytracer_amd/core.py", "raytracer_amd/impl.py", "raytracer_amd/builtin_scenes.py", "raytracer_amd/flatten.py"]
 CITE = re.compile(r"((?:[A-Za-z_.]+/)*[A-Za-z][A-Za-z0-9_]*\.cs):(\d+(?:-\d+)?(?:,\s?\d+(?:-\d+)?)*)")
 STOP = {"RenderJob", "Core", "Impl", "Hittable", "Hittables", "Material", "Materials", "Lights", "Textures", "Vector3", "Colour", "HitRecord", "Ray", "Scene",
