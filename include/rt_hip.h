@@ -381,7 +381,7 @@ typedef struct rt_scene_info {
     uint32_t n_nodes, bvh_depth;      /* inner nodes (64 B each) and deepest inner level */
     uint32_t tree_in_lds;             /* 1: the tree and sphere table are copied into each workgroup's LDS */
     uint32_t lds_image_bytes;
-    uint32_t built_on_device;         /* 1: built on the GPU (only with RT_HIP_BVH=device: Morton links, or =ploc: clustering by surface area), 0: SAH on the host (the default for every size) */
+    uint32_t built_on_device;         /* 1: built on the GPU (binned SAH, the default from 256 k bounded objects; RT_HIP_BVH=sah / =ploc / =device choose a device builder for any size), 0: SAH on the host (RT_HIP_BVH=host forces it) */
     uint32_t object_list;             /* 1: <= 16 bounded objects, traced as a list (every object for every ray, as the reference's any-hit does) instead of the tree */
     char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
 } rt_scene_info;

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -19,6 +20,7 @@
 #include "rt_bvh.h"
 namespace rtlbvh { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, std::string& err); }
 namespace rtploc { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, uint32_t* rounds, std::string& err); }
+namespace rtsah { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, uint32_t* levels, std::string& err); }
 #define RT_KERNELS_COMMON
 #include "rt_kernels.h"
 
@@ -310,14 +312,23 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rtbvh::Box b; for (int a = 0; a < 3; a++) { b.mn[a] = o.aabb_min[a]; b.mx[a] = o.aabb_max[a]; }
         boxes.push_back(b); box_obj.push_back(i);
     }
-    // Builder: binned SAH on the host (rt_bvh.cpp, subtrees on all host threads: 5 M triangles in well under a second), or on the
-    // device: RT_HIP_BVH=ploc, agglomerative clustering by surface area in Morton windows (rt_ploc.hip: SAH quality in tens of
-    // milliseconds), or RT_HIP_BVH=device, Morton order + Karras links + bottom-up refit (rt_lbvh.hip: the fastest build, but rays
-    // then do 15 % more box tests, C4: 898 -> 711 Msamples/s).  RT_HIP_BVH=host forces the host builder.
-    bool device_build = false, ploc = false;
-    if (const char* e = getenv("RT_HIP_BVH")) { ploc = !strcmp(e, "ploc"); device_build = (ploc || !strcmp(e, "device")) && boxes.size() >= 2; }
+    // Builder: binned SAH.  On the host (rt_bvh.cpp: every split position for nodes of <= 4096 objects, subtrees on all host
+    // threads) for scenes of fewer than 256 k objects — they may want the tree in LDS or as a list, which are made from the host's
+    // nodes — and on the device (rt_sah.hip: the same 16-bin algorithm breadth-first, 5 M triangles in tens of milliseconds, the
+    // nodes never cross PCIe) from there on; rays do the same number of box tests in either tree.  RT_HIP_BVH=host / =sah force
+    // one or the other; =ploc (rt_ploc.hip: clustering by surface area in Morton windows) and =device (rt_lbvh.hip: Morton order
+    // + Karras links + refit, the fastest build) are the two other device builders, both with 10-20 % more box tests per ray.
+    constexpr size_t kDeviceBuildMin = 1u << 18;
+    bool ploc = false, lbvh = false, sah = boxes.size() >= kDeviceBuildMin;
+    if (const char* e = getenv("RT_HIP_BVH")) { ploc = !strcmp(e, "ploc"); lbvh = !strcmp(e, "device"); sah = !strcmp(e, "sah") || (sah && !ploc && !lbvh && strcmp(e, "host")); }
+    const bool device_build = (ploc || lbvh || sah) && boxes.size() >= 2;
     rtbvh::BuildResult bvh;
-    if (!device_build) bvh = rtbvh::build(boxes, box_obj);
+    if (!device_build) {
+        const auto t0 = std::chrono::steady_clock::now();
+        bvh = rtbvh::build(boxes, box_obj);
+        if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: host BVH build of %zu objects: %.1f ms, depth %u\n", boxes.size(),
+                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), bvh.max_depth);
+    }
 
     // what the scene contains -> the most specific kernel variant that covers it (RT_HIP_VARIANT=generic forces the general one; test knob)
     uint32_t m_prims = 0, m_mats = 0, m_texs = 0, m_lights = 0;
@@ -403,9 +414,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         HIP_TRY(s->nodes.alloc(n_nodes * sizeof(Node)));
         std::string err;
         uint32_t rounds = 0;
-        int brc = ploc ? rtploc::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, &rounds, err)
+        const auto t0 = std::chrono::steady_clock::now();
+        int brc = sah  ? rtsah::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, &rounds, err)
+                : ploc ? rtploc::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, &rounds, err)
                        : rtlbvh::build(boxes.data(), box_obj.data(), (uint32_t)boxes.size(), s->nodes.p, &bvh.max_depth, err);
         if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "device BVH build: %s", err.c_str());
+        if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: device BVH build (%s) of %zu objects: %.1f ms, %u levels / rounds, depth %u\n", sah ? "sah" : ploc ? "ploc" : "lbvh", boxes.size(),
+                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), rounds, bvh.max_depth);
     } else UP(nodes, nodes);
     s->device_build = device_build;
     {   // leaf_code: do the tree's objects all satisfy obj_code[obj] == base + obj ?

@@ -193,9 +193,9 @@ def test_config5_hundred_thousand_spheres_64_lights(monkeypatch):
                                                           ExactLightSampling=True, ExactOcclusion=True), 0.999, monkeypatch)
 
 
-@pytest.mark.parametrize("builder", ["device", "ploc"])
+@pytest.mark.parametrize("builder", ["device", "ploc", "sah"])
 def test_config5_device_built_trees_give_the_host_trees_hits(builder, monkeypatch):
-    """100 000 spheres: the trees built on the GPU (rt_lbvh.hip, rt_ploc.hip) against the host's SAH tree — 200 k closest hits bit for
+    """100 000 spheres: the trees built on the GPU (rt_lbvh.hip, rt_ploc.hip, rt_sah.hip) against the host's SAH tree — 200 k closest hits bit for
     bit (K included: the leaf boxes and intersectors are the same, only the order of the tests differs) and 200 k any-hit answers."""
     sc = bs.ManySpheresManyLights(); flat = flatten_scene(sc)
     host = rt.DeviceScene(flat)

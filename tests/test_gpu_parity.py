@@ -253,10 +253,10 @@ def test_debug_visualisations_match_the_oracle(pairs, name, vis):
     assert close > 0.985, f"{VIS_NAMES[vis]} on {name}: only {close:.4f} of pixels match"
 
 
-@pytest.mark.parametrize("builder", ["device", "ploc"])
+@pytest.mark.parametrize("builder", ["device", "ploc", "sah"])
 @pytest.mark.parametrize("name", ["Testing", "MiniMesh", "MiniManyLights", "Zoo", "RgbSpheres"])
 def test_device_built_tree_gives_the_same_hits(pairs, name, builder, monkeypatch):
-    """RT_HIP_BVH=device: Morton-order build on the GPU (rt_lbvh.hip); =ploc: clustering by surface area (rt_ploc.hip).  Another tree,
+    """RT_HIP_BVH=device: Morton-order build on the GPU (rt_lbvh.hip); =ploc: clustering by surface area (rt_ploc.hip); =sah: binned SAH (rt_sah.hip, the default from 256 k objects).  Another tree,
     the same closest hits and any-hit answers."""
     sc, flat, dev_host, orc = pairs(name)
     monkeypatch.setenv("RT_HIP_BVH", builder)
