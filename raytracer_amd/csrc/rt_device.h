@@ -1168,13 +1168,22 @@ RT_FN ShadowRay light_shadow_ray(const SceneDev& sc, const rt_light* l, f3 wp, f
 
 // Camera.GetRay, Core/Camera.cs:35-42 with RandUtils.RandomInUnitCircle, Core/RandUtils.cs:53-59
 RT_FN Ray camera_ray(const rt_camera& cam, float u, float v, float thetaU, float rU) {
-    float theta = 0 + (((2 * PI_F) - 0) * thetaU);
-    float rr = sqrtf(rU);
-    float sx = sinf(theta), cy = cosf(theta);
-    float randX = (rr * sx) * cam.lens_radius, randY = (rr * cy) * cam.lens_radius;
     f3 U = mk3(cam.u[0], cam.u[1], cam.u[2]), V = mk3(cam.v[0], cam.v[1], cam.v[2]);
-    f3 offset = (U * randX) + (V * randY);
-    f3 origin = mk3(cam.look_from[0], cam.look_from[1], cam.look_from[2]) + offset;
+    f3 origin = mk3(cam.look_from[0], cam.look_from[1], cam.look_from[2]);
+    // A pinhole (LensRadius 0, every builtin scene): the reference still draws the point on the lens and multiplies it by 0, so the
+    // offset is (+-0, +-0, +-0) and LookFrom + offset is LookFrom bit for bit — unless a component of LookFrom is -0 (-0 + +0 = +0)
+    // or the basis is not finite (0 * inf): then, and for a real lens, the arithmetic is done.  (Wave-uniform: the sincos and the
+    // square root are a third of what making a camera ray costs, and depth 0 makes it twice, rt_kernels.h: primary_ray.)
+    const bool pinhole = cam.lens_radius == 0.0f && isfinite(U.x) && isfinite(U.y) && isfinite(U.z) && isfinite(V.x) && isfinite(V.y) && isfinite(V.z) &&
+                         !(origin.x == 0.0f && __builtin_signbitf(origin.x)) && !(origin.y == 0.0f && __builtin_signbitf(origin.y)) && !(origin.z == 0.0f && __builtin_signbitf(origin.z));
+    if (!pinhole) {
+        float theta = 0 + (((2 * PI_F) - 0) * thetaU);
+        float rr = sqrtf(rU);
+        float sx = sinf(theta), cy = cosf(theta);
+        float randX = (rr * sx) * cam.lens_radius, randY = (rr * cy) * cam.lens_radius;
+        f3 offset = (U * randX) + (V * randY);
+        origin = origin + offset;
+    }
     f3 llc = mk3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
     f3 hor = mk3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]), ver = mk3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
     f3 direction = (llc + (u * hor) + (v * ver)) - origin;

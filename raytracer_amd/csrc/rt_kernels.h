@@ -51,6 +51,7 @@ struct RenderDev {
     uint32_t max_depth, light_samples;
     uint32_t compact_requests;        // shadow requests of surviving paths are 16 B and point at the survivor's state (req_head): no Phong material, no debug visualisation
     uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
+    uint32_t implicit_primary;        // depth 0 has no stored path state: k_closest and k_shade make the camera ray of a path from its number (primary_ray)
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
@@ -106,9 +107,9 @@ RT_FN void stat_add_closest(unsigned long long* stats, uint32_t rays, const Trav
 // trees in LDS: where the tree is read through the caches the extra registers cost the traversal more than k_shade saves
 // (Cornell k_closest 23.8 -> 30.2 for -5.0 in k_shade, 5 M triangles 84.4 -> 89.6 for -1.8).  Not in debug-visualisation
 // renders, whose misses have their own colours (k_shade<CfgAll, true> keeps them).  g1w = the path's second state word (dir.y, dir.z, T.r, T.g).
-RT_FN void finish_miss(const SceneDev& sc, const RenderDev& rd, uint32_t depth, uint32_t j, f3 dir, float4 g1w) {
-    const float4 g2w = rd.st[depth & 1][2][j];
-    const uint32_t id = rd.ids[depth & 1][j].x;
+RT_FN void finish_miss(const SceneDev& sc, const RenderDev& rd, uint32_t depth, uint32_t j, f3 dir, float4 g1w, bool primary) {
+    const float4 g2w = primary ? make_float4(1.0f, 0.0f, 0.0f, 0.0f) : rd.st[depth & 1][2][j];      // (a primary path: throughput 1, nothing collected, path number = position)
+    const uint32_t id = primary ? j : rd.ids[depth & 1][j].x;
     const col3 T = mkc(g1w.z, g1w.w, g2w.x);
     col3 L = mkc(g2w.y, g2w.z, g2w.w);
     L = L + (T * sky_colour(sc, dir));
@@ -156,18 +157,26 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
     return make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
 }
 
+// RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay: the camera ray of path `id` of the batch
+// (pass id / n_pixels of the batch, pixel id % n_pixels).  A function of the path's number alone, so depth 0 needs no stored state:
+// with rd.implicit_primary the first closest-hit launch and the first k_shade launch each make the ray again (an RNG draw and a
+// sincos) instead of k_raygen writing 64 B per path that they read back 32 and 64 B of.
+RT_FN Ray primary_ray(const SceneDev& sc, const RenderDev& rd, uint32_t id) {
+    uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
+    uint32_t x = pix % rd.width, y = pix / rd.width;                                   // Decompress2DIndex, MathUtils.cs:38-43
+    RngKey key = make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
+    float4 u = rng_draw(key, 0, SLOT_CAMERA, 0);
+    float s = (float)x, t = (float)y;
+    s += plus_minus_one(u.x) * 0.5f;
+    t += plus_minus_one(u.y) * 0.5f;
+    return camera_ray(sc.camera, s / (float)rd.width, t / (float)rd.height, u.z, u.w);
+}
+
 #ifdef RT_KERNELS_COMMON      // the kernels that do not depend on the scene variant: defined by rt_lib.hip only
-// RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay
+// the stored form of depth 0 (debug visualisations, RT_HIP_RAYGEN=1)
 __global__ void __launch_bounds__(BLOCK) k_raygen(SceneDev sc, RenderDev rd) {
     for (uint32_t id = blockIdx.x * BLOCK + threadIdx.x; id < rd.n_paths; id += gridDim.x * BLOCK) {
-        uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
-        uint32_t x = pix % rd.width, y = pix / rd.width;                                   // Decompress2DIndex, MathUtils.cs:38-43
-        RngKey key = make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
-        float4 u = rng_draw(key, 0, SLOT_CAMERA, 0);
-        float s = (float)x, t = (float)y;
-        s += plus_minus_one(u.x) * 0.5f;
-        t += plus_minus_one(u.y) * 0.5f;
-        Ray r = camera_ray(sc.camera, s / (float)rd.width, t / (float)rd.height, u.z, u.w);
+        Ray r = primary_ray(sc, rd, id);
         rd.st[0][0][id] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
         rd.st[0][1][id] = make_float4(r.d.y, r.d.z, 1.0f, 1.0f);
         rd.st[0][2][id] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -206,25 +215,31 @@ RT_FN auto make_tree(const SceneDev& sc) {
 }
 
 // (Plain grid-stride loop: where rays cost about the same — Night Spheres — it beats k_closest_persistent below, 15.0 vs 17.1 ms per 184 M rays.)
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+// PRIMARY: the launch of depth 0 when the render keeps no stored state for it (rd.implicit_primary): the camera rays are made here
+// (primary_ray).  A kernel of its own so that the ray set-up does not cost the bounce launches registers (LDS tree: 57 -> 68 VGPRs
+// would leave room for one 1024-thread workgroup per CU instead of two); held to the same 8 waves per SIMD.
+template <class C, bool LDS, bool PRIMARY = false>
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, LDS && PRIMARY ? 8 : 1) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
-    const uint32_t n = rd.qcount[depth];
+    constexpr bool primary = PRIMARY;
+    const uint32_t n = primary ? rd.n_paths : rd.qcount[depth];
+    if (primary && blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = n;      // (k_shade reads it)
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
     uint32_t rays = 0, sky = 0;
     const bool finish = LDS && rd.misses_end_in_closest;       // a ray that hits nothing ends its path here (finish_miss)
     TravCount cnt = trav_count_zero();
     for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
-        float4 a = g0[j], b = g1[j];
-        Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y);
+        Ray r; float4 b;
+        if (primary) { r = primary_ray(sc, rd, j); b = make_float4(r.d.y, r.d.z, 1.0f, 1.0f); }
+        else { const float4 a = g0[j]; b = g1[j]; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y); }
         RngKey key = make_key(0, 0, 0);
-        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, g3[j].x);     // only a medium draws random numbers
+        if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, primary ? j : g3[j].x);     // only a medium draws random numbers
         Closest c = closest_hit<C>(sc, tree, r, rd.k_min, rd.k_max, key, depth, cnt);
         rd.hit[j] = make_float2(c.k, __uint_as_float(c.obj));
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) rd.hit_aux[j] = c.aux;
         rays++;
-        if (c.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, j, r.d, b); sky++; }
+        if (c.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, j, r.d, b, primary); sky++; }
     }
     stat_add_closest(rd.stats, rays, cnt, sky, depth);
 }
@@ -288,7 +303,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                 // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 via Core/RenderJob.cs:609-614
                 if (best.obj != RT_NO_HIT && !((best.k >= kMin) && (best.k <= kMax))) best.obj = RT_NO_HIT;
                 rd.hit[my_j] = make_float2(best.k, __uint_as_float(best.obj));
-                if (best.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, my_j, r.d, g1[my_j]); sky++; }
+                if (best.obj == RT_NO_HIT && finish) { finish_miss(sc, rd, depth, my_j, r.d, g1[my_j], false); sky++; }
                 active = false;
             }
             const uint32_t j = next + (uint32_t)__popcll(idle & lt_mask);
@@ -370,6 +385,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool can_survive = depth < rd.max_depth;
+    const bool primary = !VIS && rd.implicit_primary && depth == 0;
     for (uint32_t tile = blockIdx.x * TILE; tile < n; tile += gridDim.x * TILE) {     // uniform per block
       uint32_t m_surv = 0, m_shad = 0, m_hit = 0;
 #pragma unroll
@@ -412,11 +428,16 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
         // (a path whose ray hit nothing was finished by the closest-hit kernel — finish_miss — and its state is not even loaded here;
         //  debug visualisations colour their misses themselves)
         if (j < n && (VIS || !rd.misses_end_in_closest || ((m_hit >> item) & 1u))) {
-            const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j]; const uint2 a3 = rd.ids[cur][j];
+            Ray r; col3 T, L; uint2 a3;
+            if (primary) {                                                               // nothing stored for depth 0: the camera ray again (primary_ray)
+                r = primary_ray(sc, rd, j); T = mkc(1, 1, 1); L = mkc(0, 0, 0); a3 = make_uint2(j, pack_mats(RT_NO_HIT, RT_NO_HIT));
+            } else {
+                const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j]; a3 = rd.ids[cur][j];
+                r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
+                T = mkc(a1.z, a1.w, a2.x);
+                L = mkc(a2.y, a2.z, a2.w);
+            }
             const float2 hk = rd.hit[j];
-            Ray r; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);
-            col3 T = mkc(a1.z, a1.w, a2.x);
-            col3 L = mkc(a2.y, a2.z, a2.w);
             const uint32_t id = a3.x;
             Closest c; c.k = hk.x; c.obj = __float_as_uint(hk.y); c.aux = 0.0f;
             if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) { if (rd.hit_aux) c.aux = rd.hit_aux[j]; }      // (the debug-visualisation kernel is the generic one on every scene; a render of a scene without media has no hit_aux)
@@ -904,12 +925,14 @@ struct KernelSet {
     void (*shadow_rays_lds_exact)(SceneDev, RenderDev, uint32_t);
     void (*trace_closest_lds)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
     void (*trace_any_lds)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+    void (*closest_primary)(SceneDev, RenderDev, uint32_t);        // depth 0 from the path number (k_closest<.., PRIMARY>)
+    void (*closest_primary_lds)(SceneDev, RenderDev, uint32_t);
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
                 k_closest_persistent<C, false>, k_shadow_persistent<C, false>, k_shadow<C, false, true>, k_shadow_persistent<C, false, true>, nullptr,
-                nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr};
-    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+                nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr, k_closest<C, false, true>, nullptr};
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.closest_primary_lds = k_closest<C, true, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }
 

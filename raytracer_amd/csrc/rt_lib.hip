@@ -121,7 +121,7 @@ void bind_scene_pointers(rt_scene* s) {
 // cap rt_scene_create admits (80 KB), never to one scene's need: a second scene cannot lower the first one's limit.
 constexpr size_t LDS_TREE_CAP = 80 * 1024;
 int allow_big_lds(const KernelSet* ks) {
-    const void* fns[7] = {(const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
+    const void* fns[8] = {(const void*)ks->closest_primary_lds, (const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
                           (const void*)ks->shadow_rays_lds, (const void*)ks->shadow_rays_lds_exact};
     for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
     return RT_OK;
@@ -896,11 +896,14 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     // request twice and the two barriers — and 100 k spheres + 64 lights 570 (persistent request lanes) -> 768: a wave that IS one
     // request waits for the longest of its 64 rays.  Hence: trees outside LDS, requests of fewer than 32 rays.
     const bool ray_lanes = ray_lanes_ok && (s->shadow_rays >= 0 ? s->shadow_rays != 0 : (s->persistent_shadow < 0 && !s->use_lds && per_request < 32));
-    { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
+    // depth 0 without stored state (rt_kernels.h: primary_ray) unless a debug visualisation's kernel reads it (RT_HIP_RAYGEN=1: the stored form, for A/B runs)
+    rd.implicit_primary = (vis == RT_VIS_NONE && !getenv("RT_HIP_RAYGEN")) ? 1u : 0u;
+    if (!rd.implicit_primary) { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
-          if (s->use_lds) hipLaunchKernelGGL(ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
-          else hipLaunchKernelGGL(s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
+          const bool prim = rd.implicit_primary && depth == 0;
+          if (s->use_lds) hipLaunchKernelGGL(prim ? ks->closest_primary_lds : ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
+          else hipLaunchKernelGGL(prim ? ks->closest_primary : s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_tree_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_tree_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);

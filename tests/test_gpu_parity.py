@@ -445,3 +445,30 @@ def test_a_debug_visualisation_of_a_scene_without_media_has_no_shader_data_to_re
         job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, _ = job.ReadAccum(); job.Dispose()
         ref, _ = orc.render(opt, threads=4)
         assert (np.abs(got - ref) <= 2e-3 * np.maximum(np.abs(ref), 1e-2) + 1e-5).all(axis=2).mean() > 0.985
+
+
+@pytest.mark.parametrize("look_from,lens", [((-0.0, 0.5, 5.0), 0.0), ((0.0, -0.0, 5.0), 0.0), ((1.0, 0.5, 5.0), 0.0), ((-0.0, 0.5, 5.0), 0.05), ((1.0, 0.5, 5.0), -0.0)])
+def test_camera_rays_of_an_empty_scene_bit_for_bit(look_from, lens):
+    """Camera.GetRay (Core/Camera.cs:35-42) draws a point on the lens even when LensRadius is 0; the device skips that arithmetic for
+    a pinhole unless a LookFrom component is -0 (where adding the +-0 offset is not the identity).  With nothing in the scene a pixel
+    is the sky colour of its camera ray: for a pinhole the sums must equal the oracle's bit for bit, depth 0 made from the path
+    number (the default) and stored by k_raygen (debug visualisations use that form; RT_HIP_RAYGEN=1 here)."""
+    import os
+    from raytracer_amd.core import Camera, Scene
+    from raytracer_amd.impl import DefaultSkyBox
+    sc = Scene("Empty", Camera.Create(look_from, (0.3, 0.1, 0.0), (0, 1, 0), 40, 16.0 / 9.0, lens, 5.0), [], [], DefaultSkyBox())
+    flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    opt = RenderOptions(RenderWidth=64, RenderHeight=36, Passes=3, MaxBounceDepth=2, Seed=77)
+    ref, _ = orc.render(opt, threads=2)
+    for stored in ("", "1"):
+        if stored: os.environ["RT_HIP_RAYGEN"] = stored
+        try:
+            job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+            got = job.ReadAccum()[0]; job.Dispose()
+        finally:
+            os.environ.pop("RT_HIP_RAYGEN", None)
+        if lens == 0.0:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"stored={stored!r}: {(got != ref).sum()} sums differ"
+        else:       # a real lens: sinf / cosf of the device's and the host's maths libraries differ by an ulp now and then
+            assert (got != ref).mean() < 2e-3 and np.allclose(got, ref, rtol=1e-5, atol=0), f"stored={stored!r}: {(got != ref).sum()} sums differ"
+    dev.Dispose()
