@@ -12,14 +12,16 @@ Calibration (MI355X_MICROARCH.md, HBM section, and tools/calib_fetch.hip -> prof
     64 B per shadow request): scripts/run_configs.py and bench.py do."""
 import csv, io, json, os, re, subprocess, sys
 out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_summary.py"), sys.argv[1]], capture_output=True, text=True).stdout
-kernels = {}
+tot = {}      # kernel class -> [launches, FETCH_SIZE KiB, WRITE_SIZE KiB]: the instantiations of one kernel (k_closest<.., PRIMARY> and the bounce form) are one class
 for r in csv.DictReader(io.StringIO(out)):
     m = re.search(r"k_[a-z_]+", r["kernel"])
     if not m or not r.get("FETCH_SIZE") or not r.get("WRITE_SIZE"):
         continue
-    name = m.group(0)
-    n = int(r["dispatches"])
-    f, w = float(r["FETCH_SIZE"]) * 1024 / n, float(r["WRITE_SIZE"]) * 1024 / n
+    t = tot.setdefault(m.group(0), [0, 0.0, 0.0])
+    t[0] += int(r["dispatches"]); t[1] += float(r["FETCH_SIZE"]); t[2] += float(r["WRITE_SIZE"])
+kernels = {}
+for name, (n, fk, wk) in tot.items():
+    f, w = fk * 1024 / n, wk * 1024 / n
     gather = name.startswith(("k_closest", "k_shadow", "k_trace"))
     kernels[name] = {"launches_profiled": n, "fetch_size_bytes_per_launch": f, "write_size_bytes_per_launch": w, "fetch_factor": 1 if gather else 2,
                      "hbm_bytes_per_launch": (1 if gather else 2) * f + w}
