@@ -407,7 +407,9 @@ int rt_render_stats(rt_render* render, rt_stats* out);
 
 /* Per-kernel timing of the trace loop, measured with HIP events on the stream the kernels are launched on.
  * No reference counterpart (the reference only keeps a Stopwatch, RenderJob.cs:72,124); bench.py's roofline
- * figures come from here.  Off by default; while on, every launch is bracketed by two event records. */
+ * figures come from here.  Off by default; while on, every launch is bracketed by two event records.
+ * (RT_K_RAYGEN stays 0 in an ordinary render: the first closest-hit and shading launches make the camera rays themselves;
+ * only debug visualisations store them with a kernel of their own.) */
 typedef enum rt_kernel_class {
     RT_K_RAYGEN = 0, RT_K_CLOSEST = 1, RT_K_SHADE = 2, RT_K_SHADOW = 3, RT_K_ACCUMULATE = 4, RT_K_RESOLVE = 5, RT_K_COUNT = 6
 } rt_kernel_class;
