@@ -211,6 +211,15 @@ def test_config5_device_built_trees_give_the_host_trees_hits(builder, monkeypatc
     helpers.assert_closest_parity(a, b)
     kmin = np.full(len(o), 0.01, np.float32); kmax = rs.uniform(0.5, 60.0, len(o)).astype(np.float32)
     assert np.array_equal(dev.TraceAny(o, d, kmin, kmax), host.TraceAny(o, d, kmin, kmax))
+    if builder == "sah":
+        # the SAH builder is the default for big scenes because its tree costs rays what the host's costs them (VERDICT r01 item 8:
+        # within 5 %): box tests per closest ray and per shadow ray of a small render, both trees
+        opt = RenderOptions(RenderWidth=320, RenderHeight=180, Passes=1, MaxBounceDepth=10, LightSampleCountHint=1, Seed=5)
+        per_ray = []
+        for scene in (dev, host):
+            job = rt.RenderJob(sc, opt, device_scene=scene); job.Wait(); st = job.UpdateStats(); job.Dispose()
+            per_ray.append((st.NodeVisits / st.RayCount, st.ShadowNodeVisits / st.ShadowRays))
+        assert per_ray[0][0] <= 1.05 * per_ray[1][0] and per_ray[0][1] <= 1.05 * per_ray[1][1], per_ray
     dev.Dispose(); host.Dispose()
 
 
