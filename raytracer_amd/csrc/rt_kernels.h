@@ -571,6 +571,9 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
 #ifndef RT_SHADOW_LDS_WAVES
 #define RT_SHADOW_LDS_WAVES 4
 #endif
+#ifndef RT_SKIP_MUTE_RAYS
+#define RT_SKIP_MUTE_RAYS 1
+#endif
 // waves per SIMD k_shadow is held to when the tree is read from HBM, per variant (none specialised: holding the Cornell variant to
 // 4 waves = 128 VGPRs instead of its 157 spills 22 of them and is slower, 56.9 vs 53.5 ms per batch)
 template <class C> struct ShadowTune { static constexpr int min_waves = 1; };
@@ -606,9 +609,17 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, sub);
                 rays++;
                 col3 c = mkc(0, 0, 0);
+                if (!phong) {
+                    // What the light adds if nothing is in the way is known before the ray is traced.  When the running sum does not
+                    // change by it (a light beyond its cutoff, or one so dim next to what is already there that the addition rounds
+                    // back — the far lights of a many-light scene), occluded and unoccluded give the same bits: the ray is not traced.
+                    const col3 unoccluded = light_contribution<EXACT>(l, sr.kMax), t = sum + unoccluded;
+                    if (RT_SKIP_MUTE_RAYS && t.r == sum.r && t.g == sum.g && t.b == sum.b) continue;
+                    if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) sum = t;
+                    continue;
+                }
                 if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
-                if (!phong) sum = sum + c;
-                else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                         // PhongMaterial.cs:50-65
+                if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                              // PhongMaterial.cs:50-65
                     ShadowRay s2 = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT_RAW, sub);
                     rays++;
                     col3 c2 = any_hit<C>(sc, tree, s2.r, s2.kMin, s2.kMax, rd.any_cap, cnt) ? mkc(0, 0, 0) : mkc(l->colour[0], l->colour[1], l->colour[2]);
@@ -724,6 +735,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     uint32_t unused = 0;
     float kMin = 0, kMax = 0;
     int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
+    int spins = 0;
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
     for (;;) {
         bool fetched = false;
@@ -786,6 +798,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
                 r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
                 rays++; flying = true; occluded = false;
+                if (RT_SKIP_MUTE_RAYS && !phong) {                              // a ray whose light cannot change the sum is not traced (see k_shadow): accounted as if occluded, the same bits
+                    const col3 unoccluded = light_contribution<EXACT>(sc.lights + li, kMax), t = sum + unoccluded;
+                    occluded = t.r == sum.r && t.g == sum.g && t.b == sum.b;
+                }
                 for (uint32_t i = 0; i < sc.n_unbounded && !occluded; i++) {
                     uint32_t code = sc.obj_code[sc.unbounded[i]]; prims++;
                     occluded = fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
@@ -805,6 +821,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
             if (!__any(flying) && next >= end) break;
             continue;                                                           // (rays decided without the tree: account, draw again)
         }
+        // many lanes whose ray was decided without the tree (muted lights, the ground plane): serve them again before anybody traverses
+        if (RT_SKIP_MUTE_RAYS && spins < 3 && __popcll(__ballot(flying && cur == TRAV_DONE && pend == TRAV_DONE)) >= REFILL_MIN_TAKERS) { spins++; continue; }
+        spins = 0;
         for (;;) {
             while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
             if (pend != TRAV_DONE) {

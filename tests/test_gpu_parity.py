@@ -472,3 +472,34 @@ def test_camera_rays_of_an_empty_scene_bit_for_bit(look_from, lens):
         else:       # a real lens: sinf / cosf of the device's and the host's maths libraries differ by an ulp now and then
             assert (got != ref).mean() < 2e-3 and np.allclose(got, ref, rtol=1e-5, atol=0), f"stored={stored!r}: {(got != ref).sum()} sums differ"
     dev.Dispose()
+
+
+@pytest.mark.parametrize("cutoff", [np.inf, 25.0])
+def test_untraced_shadow_rays_change_no_bit(cutoff, monkeypatch):
+    """The request-lane shadow kernels (k_shadow, k_shadow_persistent) do not trace a shadow ray whose light cannot change the running
+    sum — beyond its CutoffRadius (SimpleLightBase.cs:56: Black whatever the ray says), or so dim next to what is already there that
+    the addition rounds back.  The ray-lane kernel (k_shadow_rays) traces every ray and adds the same numbers in the same order: the
+    three images must be equal bit for bit, the shadow-ray counts equal (a ray not traced is still a ray the reference asks), and
+    the request lanes must have walked fewer nodes."""
+    from raytracer_amd.impl import PointLight
+    from raytracer_amd.core import Scene
+    base = bs.ManySpheresManyLights(n_spheres=2000, n_lights=16)
+    lights = [PointLight(Position=tuple(l.Position), Colour=l.Colour, AttenuationRadius=8.0, CutoffRadius=cutoff) for l in base.Lights]
+    sc = Scene(base.Name, base.Camera, base.SceneObjects, lights, base.SkyBox, BulkObjects=base.BulkObjects)
+    flat = flatten_scene(sc)
+    opt = RenderOptions(RenderWidth=96, RenderHeight=54, Passes=2, MaxBounceDepth=5, LightSampleCountHint=2, Seed=31)
+    out = {}
+    for var, forced, what in (("RT_HIP_SHADOW_RAYS", "1", "rays"), ("RT_HIP_PERSISTENT_SHADOW", "0", "requests"), ("RT_HIP_PERSISTENT_SHADOW", "1", "persistent")):
+        monkeypatch.setenv(var, forced)
+        if what != "rays": monkeypatch.setenv("RT_HIP_SHADOW_RAYS", "0")
+        dev = rt.DeviceScene(flat)
+        monkeypatch.delenv(var); monkeypatch.delenv("RT_HIP_SHADOW_RAYS", raising=False)
+        job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+        out[what] = (job.ReadAccum()[0], job.UpdateStats()); job.Dispose(); dev.Dispose()
+    ref, rst = out["rays"]
+    assert rst.ShadowRays > 100_000
+    for what in ("requests", "persistent"):
+        got, st = out[what]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{what}: {(got != ref).sum()} sums differ"
+        assert (st.RayCount, st.ShadowRays) == (rst.RayCount, rst.ShadowRays)
+        assert st.ShadowNodeVisits < (0.8 if np.isfinite(cutoff) else 0.99) * rst.ShadowNodeVisits, (what, st.ShadowNodeVisits, rst.ShadowNodeVisits)
