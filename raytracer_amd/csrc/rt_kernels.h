@@ -653,8 +653,12 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
 // The contributions meet in LDS and the request's first lane adds them in ray order, 0 + c0 + c1 + ...: the same additions in
 // the same order as k_shadow, so the same bits.  Not for Phong materials (their second ray per light folds two sums): the
 // host launches it only for scenes without them, and only when R <= TB.
+// waves per SIMD the ray-lane kernel is held to when the tree is read through the caches, per variant.  The Cornell variant sits at
+// 127 VGPRs: one register more and it runs 3 waves instead of 4 (its shadow kernel 47.9 -> 56 ms per batch) — pinned, so that a
+// change elsewhere spills a register outside the loops instead of losing the wave.
+template <class C> struct ShadowRaysTune { static constexpr int min_waves = 1; };
 template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 6 : 1) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS ? (EXACT ? 1 : 6) : (EXACT ? 1 : ShadowRaysTune<C>::min_waves)) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr int TB = LDS ? LDS_BLOCK_RAYS : BLOCK;
     const auto tree = make_tree<LDS, TB>(sc);
     __shared__ float contrib[3][TB];
@@ -680,7 +684,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS && !EXACT ? 
             const rt_light* l = sc.lights + li;
             const ShadowRay sr = light_shadow_ray<C, EXACT>(sc, l, wp, nrm, key, depth, SLOT_LIGHT, q);
             rays++;
-            if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
+            // (a light that adds exactly nothing — beyond its cutoff, SimpleLightBase.cs:56 — needs no ray: the zero is the same; what the
+            //  request lanes skip on top of that, k_shadow, needs the running sum, which ray lanes do not have)
+            const col3 unoccluded = light_contribution<EXACT>(l, sr.kMax);
+            const bool mute = RT_SKIP_MUTE_RAYS && unoccluded.r == 0.0f && unoccluded.g == 0.0f && unoccluded.b == 0.0f;
+            if (!mute && !any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = unoccluded;
         }
         contrib[0][threadIdx.x] = c.r; contrib[1][threadIdx.x] = c.g; contrib[2][threadIdx.x] = c.b;
         __syncthreads();
@@ -920,6 +928,7 @@ using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_P
                        pbit(RT_MAT_STANDARD) | pbit(RT_MAT_REFRACTIVE) | pbit(RT_MAT_EMISSIVE_REFRACTIVE), pbit(RT_TEX_SOLID),
                        pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
 template <> struct ShadowPersistentTune<CfgSpheres> { static constexpr int min_waves = 5; };
+template <> struct ShadowRaysTune<CfgBoxes> { static constexpr int min_waves = 4; };
 using CfgAll     = Cfg<(1u << RT_HIT_TYPE_COUNT) - 1, 0x1Fu, 0x7u, 0x7u>;
 
 struct KernelSet {

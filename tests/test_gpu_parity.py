@@ -498,8 +498,15 @@ def test_untraced_shadow_rays_change_no_bit(cutoff, monkeypatch):
         out[what] = (job.ReadAccum()[0], job.UpdateStats()); job.Dispose(); dev.Dispose()
     ref, rst = out["rays"]
     assert rst.ShadowRays > 100_000
+    if np.isfinite(cutoff):     # the ray lanes leave out the rays beyond the cutoff too (an exact zero needs no running sum)
+        assert rst.ShadowNodeVisits < 0.9 * test_untraced_shadow_rays_change_no_bit.all_traced, (rst.ShadowNodeVisits, test_untraced_shadow_rays_change_no_bit.all_traced)
+    else:
+        test_untraced_shadow_rays_change_no_bit.all_traced = rst.ShadowNodeVisits
     for what in ("requests", "persistent"):
         got, st = out[what]
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{what}: {(got != ref).sum()} sums differ"
         assert (st.RayCount, st.ShadowRays) == (rst.RayCount, rst.ShadowRays)
-        assert st.ShadowNodeVisits < (0.8 if np.isfinite(cutoff) else 0.99) * rst.ShadowNodeVisits, (what, st.ShadowNodeVisits, rst.ShadowNodeVisits)
+        # (infinite cutoff: only the request lanes leave rays out — those that round back; finite: everybody leaves out the exact zeros, the bulk.
+        #  Node counts are not comparable to the last digit: the queue order, and with it the wave votes of the traversal, varies from run to run)
+        if np.isfinite(cutoff): assert st.ShadowNodeVisits < 0.9 * test_untraced_shadow_rays_change_no_bit.all_traced, (what, st.ShadowNodeVisits)
+        else: assert st.ShadowNodeVisits < 0.99 * rst.ShadowNodeVisits, (what, st.ShadowNodeVisits, rst.ShadowNodeVisits)
