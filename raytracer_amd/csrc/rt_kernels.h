@@ -929,6 +929,10 @@ using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_P
                        pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
 template <> struct ShadowPersistentTune<CfgSpheres> { static constexpr int min_waves = 5; };
 template <> struct ShadowRaysTune<CfgBoxes> { static constexpr int min_waves = 4; };
+#ifndef RT_MESH_RAYS_WAVES
+#define RT_MESH_RAYS_WAVES 5
+#endif
+template <> struct ShadowRaysTune<CfgMesh> { static constexpr int min_waves = RT_MESH_RAYS_WAVES; };
 using CfgAll     = Cfg<(1u << RT_HIT_TYPE_COUNT) - 1, 0x1Fu, 0x7u, 0x7u>;
 
 struct KernelSet {
