@@ -51,6 +51,7 @@ struct RenderDev {
     uint32_t max_depth, light_samples;
     uint32_t compact_requests;        // shadow requests of surviving paths are 16 B and point at the survivor's state (req_head): no Phong material, no debug visualisation
     uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
+    uint32_t skip_mute_rays;          // the shadow kernels first ask whether a light can change the sum at all (more than two rays per request, or a light with a cutoff)
     uint32_t implicit_primary;        // depth 0 has no stored path state: k_closest and k_shade make the camera ray of a path from its number (primary_ray)
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
@@ -613,9 +614,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
                     // What the light adds if nothing is in the way is known before the ray is traced.  When the running sum does not
                     // change by it (a light beyond its cutoff, or one so dim next to what is already there that the addition rounds
                     // back — the far lights of a many-light scene), occluded and unoccluded give the same bits: the ray is not traced.
-                    const col3 unoccluded = light_contribution<EXACT>(l, sr.kMax), t = sum + unoccluded;
-                    if (RT_SKIP_MUTE_RAYS && t.r == sum.r && t.g == sum.g && t.b == sum.b) continue;
-                    if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) sum = t;
+                    // (Only the yes/no is kept across the traversal, the contribution is worked out again afterwards: registers.  The host
+                    //  asks for the check where it can pay: more than two rays per request, or a light with a cutoff.)
+                    bool mute = false;
+                    if (RT_SKIP_MUTE_RAYS && rd.skip_mute_rays) { const col3 t = sum + light_contribution<EXACT>(l, sr.kMax); mute = t.r == sum.r && t.g == sum.g && t.b == sum.b; }
+                    if (!mute && !any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) sum = sum + light_contribution<EXACT>(l, sr.kMax);
                     continue;
                 }
                 if (!any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
@@ -686,9 +689,9 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS ? (EXACT ? 1
             rays++;
             // (a light that adds exactly nothing — beyond its cutoff, SimpleLightBase.cs:56 — needs no ray: the zero is the same; what the
             //  request lanes skip on top of that, k_shadow, needs the running sum, which ray lanes do not have)
-            const col3 unoccluded = light_contribution<EXACT>(l, sr.kMax);
-            const bool mute = RT_SKIP_MUTE_RAYS && unoccluded.r == 0.0f && unoccluded.g == 0.0f && unoccluded.b == 0.0f;
-            if (!mute && !any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = unoccluded;
+            bool mute = false;
+            if (RT_SKIP_MUTE_RAYS && rd.skip_mute_rays) { const col3 u = light_contribution<EXACT>(l, sr.kMax); mute = u.r == 0.0f && u.g == 0.0f && u.b == 0.0f; }
+            if (!mute && !any_hit<C>(sc, tree, sr.r, sr.kMin, sr.kMax, rd.any_cap, cnt)) c = light_contribution<EXACT>(l, sr.kMax);
         }
         contrib[0][threadIdx.x] = c.r; contrib[1][threadIdx.x] = c.g; contrib[2][threadIdx.x] = c.b;
         __syncthreads();
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
                 r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
                 rays++; flying = true; occluded = false;
-                if (RT_SKIP_MUTE_RAYS && !phong) {                              // a ray whose light cannot change the sum is not traced (see k_shadow): accounted as if occluded, the same bits
+                if (RT_SKIP_MUTE_RAYS && rd.skip_mute_rays && !phong) {         // a ray whose light cannot change the sum is not traced (see k_shadow): accounted as if occluded, the same bits
                     const col3 unoccluded = light_contribution<EXACT>(sc.lights + li, kMax), t = sum + unoccluded;
                     occluded = t.r == sum.r && t.g == sum.g && t.b == sum.b;
                 }
@@ -929,6 +932,7 @@ using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_P
                        pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
 template <> struct ShadowPersistentTune<CfgSpheres> { static constexpr int min_waves = 5; };
 template <> struct ShadowRaysTune<CfgBoxes> { static constexpr int min_waves = 4; };
+template <> struct ShadowPersistentTune<CfgBoxes> { static constexpr int min_waves = 4; };       // (128 VGPRs as it was; 129 with the check for lights that cannot matter)
 #ifndef RT_MESH_RAYS_WAVES
 #define RT_MESH_RAYS_WAVES 5
 #endif

@@ -92,6 +92,7 @@ struct rt_scene {
     bool device_build = false;       // the tree was built by rt_lbvh.hip
     int shadow_rays = -1;            // one lane per shadow ray (k_shadow_rays): -1 = the library's rule, 0/1 = RT_HIP_SHADOW_RAYS
     bool has_phong = false;          // a Phong material somewhere: k_shadow_rays cannot fold its two sums
+    bool any_light_cutoff = false;   // a light with a finite CutoffRadius: rays beyond it add an exact zero and are not traced
     int persistent_shadow = -1;      // shadow rays through k_shadow_persistent: -1 = by the number of rays per request, 0/1 = RT_HIP_PERSISTENT_SHADOW
     bool persistent = false;         // bounce rays through k_closest_persistent (scenes with a heavy-tailed cost per ray)
     uint32_t n_objects = 0, n_lights = 0;
@@ -543,6 +544,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
     { const char* e = getenv("RT_HIP_SHADOW_RAYS"); s->shadow_rays = e ? (e[0] == '1') : -1; }
     s->has_phong = (m_mats >> RT_MAT_PHONG) & 1u;
+    for (uint32_t i = 0; i < d->n_lights; i++) s->any_light_cutoff = s->any_light_cutoff || std::isfinite(d->lights[i].cutoff_radius);
     { const char* e = getenv("RT_HIP_PERSISTENT"); s->persistent = e ? e[0] == '1' : (!s->use_lds && n_nodes * sizeof(Node) > (64u << 20)); }
     *out = s.release();
     return RT_OK;
@@ -576,7 +578,7 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     if (int rc = scratch_for_device(device)) return rc;
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
-    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->persistent = src->persistent;
+    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
     s->n_objects = src->n_objects; s->n_lights = src->n_lights;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -811,6 +813,7 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.compact_requests = (!s->has_phong && o->debug_visualisation == RT_VIS_NONE && !getenv("RT_HIP_FULL_REQUESTS")) ? 1u : 0u;
         rd.misses_end_in_closest = (s->use_lds && o->debug_visualisation == RT_VIS_NONE) ? 1u : 0u;
         rd.any_cap = r->exact_occlusion ? INFINITY : RT_ANY_GROWTH_CAP;
+        rd.skip_mute_rays = ((uint64_t)rd.light_samples * s->n_lights > 2 || s->any_light_cutoff) ? 1u : 0u;
         rd.vis = o->debug_visualisation;
     }
     r->rd = r->slots[0].rd;
