@@ -98,6 +98,7 @@ constexpr uint32_t OBJ_INDEX_MASK = (1u << OBJ_TYPE_SHIFT) - 1;
 struct SceneDev {
     const Node*    nodes;        uint32_t n_nodes;
     uint32_t any_near_first;     // any-hit traversal visits the nearer child first (trees of >= 1024 nodes)
+    const float4* obj_shade;     // per object (albedo or tint rgb, f[0]) (emission rgb, type | flags << 8): scenes of solid-colour textures, few enough objects for the table to stay cached; else null
     const Node*    list;         uint32_t n_list_pairs;  // scenes of a few objects: every bounded object, two per record, instead of the tree (see list_closest)
     const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
     uint32_t leaf_code_affine, leaf_code_base;   // every object in the tree: obj_code[obj] == leaf_code_base + obj (see leaf_code)

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
 // reserves both output ranges with ONE atomic each, and then shades; positions inside the tile keep the input order.
 constexpr int SHADE_ITEMS = 8;
 #ifndef RT_SHADE_MIN_WAVES
-#define RT_SHADE_MIN_WAVES 1
+#define RT_SHADE_MIN_WAVES 4
 #endif
 constexpr int SHADE_MIN_WAVES = RT_SHADE_MIN_WAVES;
 
@@ -454,19 +454,29 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) n_warn++;                      // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
                 if constexpr (VIS) { if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) uv_warn++; }   // CheckUVCoordValid
                 const rt_material* m = sc.materials + h.mat;
+                // The hit's shading record (small scenes whose textures are all solid colours: obj_shade): what the material and its
+                // two textures say, resolved per object by the host — one gather next to the primitive's instead of the chain
+                // object -> material -> textures.  Same numbers either way.
+                const bool flat = !VIS && sc.obj_shade != nullptr;
+                float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+                if (flat) { s0 = sc.obj_shade[2 * c.obj]; s1 = sc.obj_shade[2 * c.obj + 1]; }
+                const uint32_t mtype = flat ? (__float_as_uint(s1.w) & 0xFFu) : m->type, mflags = flat ? (__float_as_uint(s1.w) >> 8) : m->flags;
+                const float mf0 = flat ? s0.w : m->f[0];
+                auto tex0 = [&]() { return flat ? mkc(s0.x, s0.y, s0.z) : texture_colour<C>(sc, m->tex[0], h.wp); };
+                auto tex1 = [&]() { return flat ? mkc(s1.x, s1.y, s1.z) : texture_colour<C>(sc, m->tex[1], h.wp); };
                 uint32_t prev = unpack_mat(a3.y), first = unpack_mat(a3.y >> 16);
                 float4 u = rng_draw(key, depth, SLOT_SCATTER, 0);
                 Ray nr; nr.o = h.wp; nr.d = r.d;
                 col3 a = mkc(1, 1, 1);        // multiplier of the future colour
                 col3 W = mkc(0, 0, 0);        // weight of the light sum
-                switch (m->type) {
+                switch (mtype) {
                     case RT_MAT_STANDARD: if constexpr (RT_HAS_MAT(C, RT_MAT_STANDARD)) {                                            // StandardMaterial.cs:64-80 (Scatter :64-72, CalculateColour :74-80)
                         f3 diffuse = on_unit_sphere(u.x, u.y, u.z);
                         if (dot(diffuse, h.n) < 0) diffuse = diffuse * -1.0f;
                         f3 refl = reflect(r.d, h.n);
-                        nr.d = normalize(normalize(lerp3(refl, diffuse, m->f[0])));
-                        a = texture_colour<C>(sc, m->tex[0], h.wp);
-                        L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
+                        nr.d = normalize(normalize(lerp3(refl, diffuse, mf0)));
+                        a = tex0();
+                        L = L + (T * tex1());
                         W = T * a;
                     } break;
                     case RT_MAT_PHONG: if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {                                               // PhongMaterial.cs:26-85 (Scatter :26-37, CalculateColour :39-85)
@@ -491,7 +501,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                         float cosT = minf_net(dot(-ud, h.n), 1.0f);
                         float sinT = sqrtf(1.0f - (cosT * cosT));
                         bool entering = (depth == 0) || (prev != h.mat);
-                        float eta = entering ? 1.0f : m->f[0], etaP = entering ? m->f[0] : 1.0f;
+                        float eta = entering ? 1.0f : mf0, etaP = entering ? mf0 : 1.0f;
                         float ratio = eta / etaP;
                         bool cannot = ratio * sinT > 1.0f;
                         float r0 = (eta - etaP) / (eta + etaP);
@@ -500,7 +510,7 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                         if (reflectance > u.w) cannot = true;
                         f3 out;
                         if (cannot) out = reflect(ud, h.n);
-                        else if (!(m->flags & RT_MAT_FLAG_ALTERNATE_REFRACTION)) {
+                        else if (!(mflags & RT_MAT_FLAG_ALTERNATE_REFRACTION)) {
                             f3 perp = ratio * (ud + (cosT * h.n));
                             f3 par = -sqrtf(fabsf(1.0f - length_sq(perp))) * h.n;
                             out = perp + par;
@@ -509,11 +519,11 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                             out = normalize((sqrtf((1 - powf(ratio, 2.0f)) * (1 - powf(nd, 2.0f))) * h.n) + (ratio * (ud - (nd * h.n))));
                         }
                         nr.d = normalize(out);
-                        a = texture_colour<C>(sc, m->tex[0], h.wp);
+                        a = tex0();
                         W = T * a;
-                        if (m->type == RT_MAT_EMISSIVE_REFRACTIVE) {
-                            bool emit = (m->flags & RT_MAT_FLAG_DIRECT_EMISSION) || !(depth == 0 || (depth == 1 && first == h.mat));
-                            if (emit) L = L + (T * texture_colour<C>(sc, m->tex[1], h.wp));
+                        if (mtype == RT_MAT_EMISSIVE_REFRACTIVE) {
+                            bool emit = (mflags & RT_MAT_FLAG_DIRECT_EMISSION) || !(depth == 0 || (depth == 1 && first == h.mat));
+                            if (emit) L = L + (T * tex1());
                         }
                     } break;
                 }

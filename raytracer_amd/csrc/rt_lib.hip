@@ -79,7 +79,7 @@ constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 
 // every device buffer of a scene (X-macro: allocation, peer copy to a replica, pointer binding all walk the same list)
 #define RT_SCENE_BUFFERS(X) \
-    X(nodes) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
+    X(nodes) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
     X(axis0) X(axis1) X(axis2) X(disks) X(boxes) X(capsules) X(cylinders) X(media_rec) X(materials) X(textures) X(lights)
 
 struct rt_scene {
@@ -111,6 +111,7 @@ void bind_scene_pointers(rt_scene* s) {
     SceneDev& sd = s->dev;
     sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>();
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>();
+    sd.obj_shade = s->obj_shade.bytes ? s->obj_shade.as<float4>() : nullptr;
     sd.unbounded = s->unbounded.as<uint32_t>(); sd.media = s->media.as<uint32_t>();
     sd.spheres = s->spheres.as<float4>(); sd.quads = s->quads.as<float4>(); sd.triangles = s->triangles.as<float4>(); sd.inf_planes = s->inf_planes.as<float4>();
     sd.axis_planes[0] = s->axis0.as<float4>(); sd.axis_planes[1] = s->axis1.as<float4>(); sd.axis_planes[2] = s->axis2.as<float4>();
@@ -469,6 +470,30 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         }
     }
     UP(obj_code, obj_code); UP(obj_material, obj_mat); UP(unbounded, unbounded); UP(media, media);
+    {   // Shading records per object (rt_kernels.h: k_shade): when every texture is a solid colour and every material one of the three
+        // that read (tex[0], tex[1], f[0], flags) only, what a hit needs from its material is 32 B that the host can resolve once.
+        // Not for big scenes (the table would be 32 B per object of cache misses where one material record serves millions of hits).
+        bool ok = d->n_objects > 0 && d->n_objects <= (1u << 16) && !getenv("RT_HIP_NO_OBJ_SHADE");
+        for (uint32_t i = 0; ok && i < d->n_textures; i++) ok = d->textures[i].type == RT_TEX_SOLID;
+        for (uint32_t i = 0; ok && i < d->n_materials; i++) {
+            const rt_material& m = d->materials[i];
+            ok = (m.type == RT_MAT_STANDARD || m.type == RT_MAT_REFRACTIVE || m.type == RT_MAT_EMISSIVE_REFRACTIVE) && m.tex[0] < d->n_textures &&
+                 (m.type == RT_MAT_REFRACTIVE || m.tex[1] < d->n_textures) && m.flags < (1u << 24);
+        }
+        if (ok) {
+            std::vector<float4> sh(2 * (size_t)d->n_objects);
+            for (uint32_t i = 0; i < d->n_objects; i++) {
+                const rt_material& m = d->materials[obj_mat[i]];
+                const rt_texture& t0 = d->textures[m.tex[0]];
+                const uint32_t bits = m.type | (m.flags << 8);
+                float e[3] = {0, 0, 0};
+                if (m.type != RT_MAT_REFRACTIVE) { const rt_texture& t1 = d->textures[m.tex[1]]; e[0] = t1.f[0]; e[1] = t1.f[1]; e[2] = t1.f[2]; }
+                float w; memcpy(&w, &bits, 4);
+                sh[2 * i] = make_float4(t0.f[0], t0.f[1], t0.f[2], m.f[0]); sh[2 * i + 1] = make_float4(e[0], e[1], e[2], w);
+            }
+            UP(obj_shade, sh);
+        }
+    }
     UP(spheres, spheres); UP(quads, quads); UP(triangles, tris); UP(inf_planes, planes); UP(axis0, axis[0]); UP(axis1, axis[1]); UP(axis2, axis[2]);
     UP(disks, disks); UP(boxes, bxs); UP(capsules, caps); UP(cylinders, cyls);
     std::vector<rt_medium> mrec(d->media, d->media + d->n_media);
