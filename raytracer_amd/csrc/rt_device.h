@@ -98,7 +98,7 @@ constexpr uint32_t OBJ_INDEX_MASK = (1u << OBJ_TYPE_SHIFT) - 1;
 struct SceneDev {
     const Node*    nodes;        uint32_t n_nodes;
     uint32_t any_near_first;     // any-hit traversal visits the nearer child first (trees of >= 1024 nodes)
-    const float4* obj_shade;     // per object (albedo or tint rgb, f[0]) (emission rgb, type | flags << 8): scenes of solid-colour textures, few enough objects for the table to stay cached; else null
+    const float4* obj_shade;     // per object, 64 B: (albedo or tint rgb, f[0]) (emission rgb, type | flags << 8) (sphere centre + radius, or plane normal) (obj_code, material, -, -): scenes of solid-colour textures, few enough objects for the table to stay cached; else null
     const Node*    list;         uint32_t n_list_pairs;  // scenes of a few objects: every bounded object, two per record, instead of the tree (see list_closest)
     const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
     uint32_t leaf_code_affine, leaf_code_base;   // every object in the tree: obj_code[obj] == leaf_code_base + obj (see leaf_code)
@@ -865,14 +865,17 @@ RT_FN void sphere_uv(f3 p, float& u, float& v) {                                
 }
 
 template <class C, bool WANT_UV>
-RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& key, uint32_t depth) {
-    HitRec h; h.k = c.k; h.obj = c.obj; h.mat = sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
-    uint32_t code = sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
+RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& key, uint32_t depth,
+                          bool have_rec = false, float4 rec_geo = make_float4(0, 0, 0, 0), uint32_t rec_code = 0, uint32_t rec_mat = 0) {
+    // have_rec: the caller has the object's record of sc.obj_shade (code, material, and for a sphere or an infinite plane the 16 B
+    // this function needs of the primitive): nothing is fetched here then
+    HitRec h; h.k = c.k; h.obj = c.obj; h.mat = have_rec ? rec_mat : sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
+    uint32_t code = have_rec ? rec_code : sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
     h.wp = point_at(r.o, r.d, c.k);
     h.n = mk3(0, 0, 0); h.lp = h.wp;
     switch (type) {
         case RT_HIT_SPHERE: if constexpr (RT_HAS_PRIM(C, RT_HIT_SPHERE)) {                                                            // Sphere.cs:59-70
-            float4 s = sc.spheres[idx];
+            float4 s = have_rec ? rec_geo : sc.spheres[idx];
             f3 outN = normalize(h.wp - mk3(s.x, s.y, s.z));
             bool inside = dot(r.d, outN) > 0.0f;
             h.n = inside ? -outN : outN; h.outside = !inside;
@@ -891,7 +894,7 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
             }
         } break;
         case RT_HIT_INFINITE_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_INFINITE_PLANE)) {                                                    // InfinitePlane.cs:55-60
-            float4 p1 = sc.inf_planes[2 * idx + 1];
+            float4 p1 = have_rec ? rec_geo : sc.inf_planes[2 * idx + 1];
             h.n = mk3(p1.x, p1.y, p1.z);
             h.outside = dot(r.d, h.n) < 0;
             if (WANT_UV) { float4 p0 = sc.inf_planes[2 * idx]; h.lp = h.wp - mk3(p0.x, p0.y, p0.z); }

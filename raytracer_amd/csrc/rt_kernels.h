@@ -450,16 +450,17 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 rd.out[id] = make_float4(L.r, L.g, L.b, 0.0f);
             } else {
                 RngKey key = path_key(rd, id);
-                HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth);
+                // The hit's record (small scenes whose textures are all solid colours: sc.obj_shade, one 64-B line per object): what the
+                // object's code, its primitive (a sphere or an infinite plane), its material and the material's two textures say,
+                // resolved per object by the host — one gather instead of the chains object -> primitive and object -> material ->
+                // textures.  Same numbers either way.
+                const bool flat = !VIS && sc.obj_shade != nullptr;
+                float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+                if (flat) { const float4* rec = sc.obj_shade + 4 * (size_t)c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
+                HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth, flat && __float_as_uint(s3.z) != 0u, s2, __float_as_uint(s3.x), __float_as_uint(s3.y));
                 if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) n_warn++;                      // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
                 if constexpr (VIS) { if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) uv_warn++; }   // CheckUVCoordValid
                 const rt_material* m = sc.materials + h.mat;
-                // The hit's shading record (small scenes whose textures are all solid colours: obj_shade): what the material and its
-                // two textures say, resolved per object by the host — one gather next to the primitive's instead of the chain
-                // object -> material -> textures.  Same numbers either way.
-                const bool flat = !VIS && sc.obj_shade != nullptr;
-                float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
-                if (flat) { s0 = sc.obj_shade[2 * c.obj]; s1 = sc.obj_shade[2 * c.obj + 1]; }
                 const uint32_t mtype = flat ? (__float_as_uint(s1.w) & 0xFFu) : m->type, mflags = flat ? (__float_as_uint(s1.w) >> 8) : m->flags;
                 const float mf0 = flat ? s0.w : m->f[0];
                 auto tex0 = [&]() { return flat ? mkc(s0.x, s0.y, s0.z) : texture_colour<C>(sc, m->tex[0], h.wp); };

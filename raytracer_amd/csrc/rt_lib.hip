@@ -481,15 +481,20 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                  (m.type == RT_MAT_REFRACTIVE || m.tex[1] < d->n_textures) && m.flags < (1u << 24);
         }
         if (ok) {
-            std::vector<float4> sh(2 * (size_t)d->n_objects);
+            std::vector<float4> sh(4 * (size_t)d->n_objects, make_float4(0, 0, 0, 0));
+            auto bits = [](uint32_t u) { float w; memcpy(&w, &u, 4); return w; };
             for (uint32_t i = 0; i < d->n_objects; i++) {
                 const rt_material& m = d->materials[obj_mat[i]];
                 const rt_texture& t0 = d->textures[m.tex[0]];
-                const uint32_t bits = m.type | (m.flags << 8);
                 float e[3] = {0, 0, 0};
                 if (m.type != RT_MAT_REFRACTIVE) { const rt_texture& t1 = d->textures[m.tex[1]]; e[0] = t1.f[0]; e[1] = t1.f[1]; e[2] = t1.f[2]; }
-                float w; memcpy(&w, &bits, 4);
-                sh[2 * i] = make_float4(t0.f[0], t0.f[1], t0.f[2], m.f[0]); sh[2 * i + 1] = make_float4(e[0], e[1], e[2], w);
+                sh[4 * i] = make_float4(t0.f[0], t0.f[1], t0.f[2], m.f[0]); sh[4 * i + 1] = make_float4(e[0], e[1], e[2], bits(m.type | (m.flags << 8)));
+                // what finalize_hit reads of the primitive, where that is 16 B: a sphere's (centre, radius), an infinite plane's normal
+                const rt_object& o = d->objects[i];
+                uint32_t have_geo = 0;
+                if (o.type == RT_HIT_SPHERE) { sh[4 * i + 2] = spheres[o.index]; have_geo = 1; }
+                else if (o.type == RT_HIT_INFINITE_PLANE) { sh[4 * i + 2] = planes[2 * o.index + 1]; have_geo = 1; }
+                sh[4 * i + 3] = make_float4(bits(obj_code[i]), bits(obj_mat[i]), bits(have_geo), 0.0f);
             }
             UP(obj_shade, sh);
         }
