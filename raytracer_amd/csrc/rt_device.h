@@ -867,8 +867,8 @@ RT_FN void sphere_uv(f3 p, float& u, float& v) {                                
 template <class C, bool WANT_UV>
 RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& key, uint32_t depth,
                           bool have_rec = false, float4 rec_geo = make_float4(0, 0, 0, 0), uint32_t rec_code = 0, uint32_t rec_mat = 0) {
-    // have_rec: the caller has the object's record of sc.obj_shade (code, material, and for a sphere or an infinite plane the 16 B
-    // this function needs of the primitive): nothing is fetched here then
+    // have_rec: the caller has the object's record of sc.obj_shade (code, material, and the 16 B this function needs of the primitive
+    // when it wants no UV: a sphere, a plane's or quad's or triangle's or disk's normal, an axis plane's offset): nothing is fetched here then
     HitRec h; h.k = c.k; h.obj = c.obj; h.mat = have_rec ? rec_mat : sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
     uint32_t code = have_rec ? rec_code : sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
     h.wp = point_at(r.o, r.d, c.k);
@@ -883,10 +883,11 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
         } break;
         case RT_HIT_QUAD: case RT_HIT_TRIANGLE: if constexpr (RT_HAS_PRIM(C, RT_HIT_QUAD) || RT_HAS_PRIM(C, RT_HIT_TRIANGLE)) {                                        // Quad.cs:100-119
             const float4* q = (type == RT_HIT_QUAD ? sc.quads : sc.triangles) + 4 * idx;
-            float4 q0 = q[0], q1 = q[1];
+            float4 q1 = have_rec ? rec_geo : q[1];
             h.n = mk3(q1.x, q1.y, q1.z);
             h.outside = dot(h.n, r.d) < 0;
             if (WANT_UV) {
+                float4 q0 = q[0];
                 f3 lp = h.wp - mk3(q0.x, q0.y, q0.z); float4 c1 = q[2], c2 = q[3];
                 h.u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
                 h.v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;
@@ -902,11 +903,12 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
         case RT_HIT_XY_PLANE: case RT_HIT_XZ_PLANE: case RT_HIT_YZ_PLANE: if constexpr (RT_HAS_PRIM(C, RT_HIT_XY_PLANE) || RT_HAS_PRIM(C, RT_HIT_XZ_PLANE) || RT_HAS_PRIM(C, RT_HIT_YZ_PLANE)) {              // XYPlane.cs:69-101
             int axis = type - RT_HIT_XY_PLANE;
             const float4* p = sc.axis_planes[axis] + 2 * idx;
-            float4 p0 = p[0]; float planeC = p[1].x;
+            float planeC = have_rec ? rec_geo.x : p[1].x;
             float oC = axis == 0 ? r.o.z : axis == 1 ? r.o.y : r.o.x;
             f3 unit = axis == 0 ? mk3(0, 0, 1) : axis == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0);
             h.n = oC < planeC ? -unit : unit;
             if (WANT_UV) {
+                float4 p0 = p[0];
                 float a = axis == 2 ? h.wp.y : h.wp.x, b = axis == 0 ? h.wp.y : h.wp.z;
                 h.u = (a - p0.x) / (p0.y - p0.x); h.v = (b - p0.z) / (p0.w - p0.z);
                 float ca = (p0.x + p0.y) / 2.0f, cb = (p0.z + p0.w) / 2.0f;                // XYPlane.cs:28 centre
@@ -915,10 +917,11 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
         } break;
         case RT_HIT_DISK: if constexpr (RT_HAS_PRIM(C, RT_HIT_DISK)) {                                                              // Disk.cs:83-97
             const float4* d = sc.disks + 4 * idx;
-            float4 d0 = d[0], d1 = d[1];
+            float4 d1 = have_rec ? rec_geo : d[1];
             h.n = mk3(d1.x, d1.y, d1.z);
             h.outside = dot(r.d, h.n) < 0;
             if (WANT_UV) {
+                float4 d0 = d[0];
                 f3 lp = h.wp - mk3(d0.x, d0.y, d0.z); float4 c1 = d[2], c2 = d[3];
                 float u = (lp.x * c1.x) + (lp.y * c1.y) + (lp.z * c1.z) + c1.w;
                 float v = (lp.x * c2.x) + (lp.y * c2.y) + (lp.z * c2.z) + c2.w;

@@ -489,11 +489,15 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                 float e[3] = {0, 0, 0};
                 if (m.type != RT_MAT_REFRACTIVE) { const rt_texture& t1 = d->textures[m.tex[1]]; e[0] = t1.f[0]; e[1] = t1.f[1]; e[2] = t1.f[2]; }
                 sh[4 * i] = make_float4(t0.f[0], t0.f[1], t0.f[2], m.f[0]); sh[4 * i + 1] = make_float4(e[0], e[1], e[2], bits(m.type | (m.flags << 8)));
-                // what finalize_hit reads of the primitive, where that is 16 B: a sphere's (centre, radius), an infinite plane's normal
+                // what finalize_hit reads of the primitive (no UV wanted), where that is 16 B: a sphere's (centre, radius), a normal, an axis plane's offset
                 const rt_object& o = d->objects[i];
                 uint32_t have_geo = 0;
                 if (o.type == RT_HIT_SPHERE) { sh[4 * i + 2] = spheres[o.index]; have_geo = 1; }
                 else if (o.type == RT_HIT_INFINITE_PLANE) { sh[4 * i + 2] = planes[2 * o.index + 1]; have_geo = 1; }
+                else if (o.type == RT_HIT_QUAD) { sh[4 * i + 2] = quads[4 * o.index + 1]; have_geo = 1; }
+                else if (o.type == RT_HIT_TRIANGLE) { sh[4 * i + 2] = tris[4 * o.index + 1]; have_geo = 1; }
+                else if (o.type == RT_HIT_DISK) { sh[4 * i + 2] = disks[4 * o.index + 1]; have_geo = 1; }
+                else if (o.type >= RT_HIT_XY_PLANE && o.type <= RT_HIT_YZ_PLANE) { sh[4 * i + 2] = axis[o.type - RT_HIT_XY_PLANE][2 * o.index + 1]; have_geo = 1; }
                 sh[4 * i + 3] = make_float4(bits(obj_code[i]), bits(obj_mat[i]), bits(have_geo), 0.0f);
             }
             UP(obj_shade, sh);
