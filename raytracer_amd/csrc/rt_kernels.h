@@ -52,7 +52,7 @@ struct RenderDev {
     uint32_t compact_requests;        // shadow requests of surviving paths are 16 B and point at the survivor's state (req_head): no Phong material, no debug visualisation
     uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
     uint32_t skip_mute_rays;          // the shadow kernels first ask whether a light can change the sum at all (more than two rays per request, or a light with a cutoff)
-    uint32_t implicit_primary;        // depth 0 has no stored path state: k_closest and k_shade make the camera ray of a path from its number (primary_ray)
+    uint32_t implicit_primary;        // depth 0 has no k_raygen pass: the first k_closest launch makes the camera ray of a path from its number (primary_ray); k_shade makes it again (1) or reads the 32 B k_closest left (2)
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
 };
@@ -159,9 +159,17 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
 }
 
 // RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay: the camera ray of path `id` of the batch
-// (pass id / n_pixels of the batch, pixel id % n_pixels).  A function of the path's number alone, so depth 0 needs no stored state:
-// with rd.implicit_primary the first closest-hit launch and the first k_shade launch each make the ray again (an RNG draw and a
-// sincos) instead of k_raygen writing 64 B per path that they read back 32 and 64 B of.
+// (pass id / n_pixels of the batch, pixel id % n_pixels).  A function of the path's number alone, so depth 0 needs no k_raygen
+// pass that writes 64 B of state per path for the first closest-hit launch to read back: with rd.implicit_primary that launch
+// makes the rays itself.  What the first k_shade launch needs of them it either makes again (rd.implicit_primary == 1) or reads
+// (== 2: the closest-hit launch leaves the 32 B of origin and direction; throughput 1, radiance 0 and the path number are
+// implied).  Reading is for trees in LDS, whose closest-hit kernel is bound by arithmetic and hides the stores (Night Spheres,
+// since the per-object records made k_shade arithmetic-bound too: 37.4 -> 35.2 ms per step for +0.4 in k_closest; before them,
+// while k_shade waited on its material gathers, making the ray again was free and reading cost 1 ms); where the tree is read
+// through the caches the stores cost the traversal more than k_shade saves (5 M triangles k_closest 85.1 -> 86.8 ms per batch).
+#ifndef RT_PRIMARY_STORE
+#define RT_PRIMARY_STORE 1
+#endif
 RT_FN Ray primary_ray(const SceneDev& sc, const RenderDev& rd, uint32_t id) {
     uint32_t b = id / rd.n_pixels, pix = id - b * rd.n_pixels;
     uint32_t x = pix % rd.width, y = pix / rd.width;                                   // Decompress2DIndex, MathUtils.cs:38-43
@@ -232,7 +240,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, LDS && PRIMAR
     TravCount cnt = trav_count_zero();
     for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n; j += gridDim.x * TB) {
         Ray r; float4 b;
-        if (primary) { r = primary_ray(sc, rd, j); b = make_float4(r.d.y, r.d.z, 1.0f, 1.0f); }
+        if (primary) {
+            r = primary_ray(sc, rd, j); b = make_float4(r.d.y, r.d.z, 1.0f, 1.0f);
+            if (LDS && RT_PRIMARY_STORE) { rd.st[0][0][j] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x); rd.st[0][1][j] = b; }      // the ray, for k_shade (32 of a stored state's 64 B; rd.implicit_primary == 2)
+        }
         else { const float4 a = g0[j]; b = g1[j]; r.o = mk3(a.x, a.y, a.z); r.d = mk3(a.w, b.x, b.y); }
         RngKey key = make_key(0, 0, 0);
         if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) key = path_key(rd, primary ? j : g3[j].x);     // only a medium draws random numbers
@@ -431,7 +442,9 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
         if (j < n && (VIS || !rd.misses_end_in_closest || ((m_hit >> item) & 1u))) {
             Ray r; col3 T, L; uint2 a3;
             if (primary) {                                                               // nothing stored for depth 0: the camera ray again (primary_ray)
-                r = primary_ray(sc, rd, j); T = mkc(1, 1, 1); L = mkc(0, 0, 0); a3 = make_uint2(j, pack_mats(RT_NO_HIT, RT_NO_HIT));
+                if (rd.implicit_primary == 2u) { const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j]; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y); }
+                else r = primary_ray(sc, rd, j);
+                T = mkc(1, 1, 1); L = mkc(0, 0, 0); a3 = make_uint2(j, pack_mats(RT_NO_HIT, RT_NO_HIT));
             } else {
                 const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j], a2 = rd.st[cur][2][j]; a3 = rd.ids[cur][j];
                 r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y);

@@ -934,7 +934,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     // request waits for the longest of its 64 rays.  Hence: trees outside LDS, requests of fewer than 32 rays.
     const bool ray_lanes = ray_lanes_ok && (s->shadow_rays >= 0 ? s->shadow_rays != 0 : (s->persistent_shadow < 0 && !s->use_lds && per_request < 32));
     // depth 0 without stored state (rt_kernels.h: primary_ray) unless a debug visualisation's kernel reads it (RT_HIP_RAYGEN=1: the stored form, for A/B runs)
-    rd.implicit_primary = (vis == RT_VIS_NONE && !getenv("RT_HIP_RAYGEN")) ? 1u : 0u;
+    rd.implicit_primary = (vis == RT_VIS_NONE && !getenv("RT_HIP_RAYGEN")) ? (s->use_lds && RT_PRIMARY_STORE ? 2u : 1u) : 0u;
     if (!rd.implicit_primary) { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
