@@ -102,6 +102,8 @@ struct SceneDev {
     const Node*    list;         uint32_t n_list_pairs;  // scenes of a few objects: every bounded object, two per record, instead of the tree (see list_closest)
     const uint32_t* obj_code;    // (type << 28) | index-in-type-table, per object
     uint32_t leaf_code_affine, leaf_code_base;   // every object in the tree: obj_code[obj] == leaf_code_base + obj (see leaf_code)
+    uint32_t all_code_affine;    // ... and every other object too: finalize_hit computes the code of whatever was hit
+    uint32_t uniform_material;   // the one material every object has (a mesh), or RT_NO_HIT: finalize_hit need not look it up per object, and the material's loads become scalar
     const uint32_t* obj_material;
     uint32_t n_objects;
     const uint32_t* unbounded;   uint32_t n_unbounded;   // objects with a non-finite AABB (InfinitePlane.cs:28), tested for every ray
@@ -869,8 +871,9 @@ RT_FN HitRec finalize_hit(const SceneDev& sc, Ray r, Closest c, const RngKey& ke
                           bool have_rec = false, float4 rec_geo = make_float4(0, 0, 0, 0), uint32_t rec_code = 0, uint32_t rec_mat = 0) {
     // have_rec: the caller has the object's record of sc.obj_shade (code, material, and the 16 B this function needs of the primitive
     // when it wants no UV: a sphere, a plane's or quad's or triangle's or disk's normal, an axis plane's offset): nothing is fetched here then
-    HitRec h; h.k = c.k; h.obj = c.obj; h.mat = have_rec ? rec_mat : sc.obj_material[c.obj]; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
-    uint32_t code = have_rec ? rec_code : sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
+    HitRec h; h.k = c.k; h.obj = c.obj; h.u = 0; h.v = 0; h.shader = 0; h.outside = true;
+    h.mat = have_rec ? rec_mat : sc.uniform_material != RT_NO_HIT ? sc.uniform_material : sc.obj_material[c.obj];
+    uint32_t code = have_rec ? rec_code : sc.all_code_affine ? sc.leaf_code_base + c.obj : sc.obj_code[c.obj], type = code >> OBJ_TYPE_SHIFT; size_t idx = code & OBJ_INDEX_MASK;
     h.wp = point_at(r.o, r.d, c.k);
     h.n = mk3(0, 0, 0); h.lp = h.wp;
     switch (type) {

@@ -430,6 +430,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const uint32_t base = affine ? obj_code[box_obj[0]] - box_obj[0] : 0u;
         for (uint32_t obj : box_obj) if (obj_code[obj] - obj != base) { affine = false; break; }
         s->dev.leaf_code_affine = affine ? 1u : 0u; s->dev.leaf_code_base = base;
+        bool all = affine;
+        for (uint32_t i = 0; all && i < d->n_objects; i++) all = obj_code[i] - i == base;
+        s->dev.all_code_affine = all ? 1u : 0u;
+        bool one = d->n_objects > 0;
+        for (uint32_t i = 1; one && i < d->n_objects; i++) one = obj_mat[i] == obj_mat[0];
+        s->dev.uniform_material = one ? obj_mat[0] : RT_NO_HIT;
     }
     // a handful of objects: a list of all of them, two per record, instead of the tree (rt_device.h: list_closest)
     {
