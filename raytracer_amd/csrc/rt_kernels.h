@@ -164,7 +164,7 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
 // makes the rays itself.  What the first k_shade launch needs of them it either makes again (rd.implicit_primary == 1) or reads
 // (== 2: the closest-hit launch leaves the 32 B of origin and direction; throughput 1, radiance 0 and the path number are
 // implied).  Reading is for trees in LDS, whose closest-hit kernel is bound by arithmetic and hides the stores (Night Spheres,
-// since the per-object records made k_shade arithmetic-bound too: 37.4 -> 35.2 ms per step for +0.4 in k_closest; before them,
+// since the per-object records made k_shade arithmetic-bound too: 38.8 -> 37.3 ms per step for +0.7 in k_closest; before them,
 // while k_shade waited on its material gathers, making the ray again was free and reading cost 1 ms); where the tree is read
 // through the caches the stores cost the traversal more than k_shade saves (5 M triangles k_closest 85.1 -> 86.8 ms per batch).
 #ifndef RT_PRIMARY_STORE
