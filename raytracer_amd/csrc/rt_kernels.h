@@ -51,6 +51,7 @@ struct RenderDev {
     uint32_t max_depth, light_samples;
     uint32_t compact_requests;        // shadow requests of surviving paths are 16 B and point at the survivor's state (req_head): no Phong material, no debug visualisation
     uint32_t misses_end_in_closest;   // the closest-hit kernels finish the paths that hit nothing (finish_miss): tree in LDS, no debug visualisation
+    uint32_t obj_shade_lds_bytes;     // k_shade copies the table of object records (sc.obj_shade) into LDS first: this many bytes, 0 = reads it through the caches
     uint32_t skip_mute_rays;          // the shadow kernels first ask whether a light can change the sum at all (more than two rays per request, or a light with a cutoff)
     uint32_t implicit_primary;        // depth 0 has no k_raygen pass: the first k_closest launch makes the camera ray of a path from its number (primary_ray); k_shade makes it again (1) or reads the 32 B k_closest left (2)
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
@@ -398,6 +399,13 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool can_survive = depth < rd.max_depth;
     const bool primary = !VIS && rd.implicit_primary && depth == 0;
+    // a table of object records small enough (a few hundred objects) is copied into the workgroup's LDS: the gather per hit is then an LDS read
+    const bool rec_lds = !VIS && rd.obj_shade_lds_bytes != 0;
+    if (rec_lds) {
+        uint4* dst = (uint4*)lds_stack; const uint4* src = (const uint4*)sc.obj_shade;
+        for (uint32_t i = threadIdx.x; i < rd.obj_shade_lds_bytes / 16; i += BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
     for (uint32_t tile = blockIdx.x * TILE; tile < n; tile += gridDim.x * TILE) {     // uniform per block
       uint32_t m_surv = 0, m_shad = 0, m_hit = 0;
 #pragma unroll
@@ -469,7 +477,8 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 // textures.  Same numbers either way.
                 const bool flat = !VIS && sc.obj_shade != nullptr;
                 float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
-                if (flat) { const float4* rec = sc.obj_shade + 4 * (size_t)c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
+                if (flat && rec_lds) { const float4* rec = (const float4*)lds_stack + 4 * c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
+                else if (flat) { const float4* rec = sc.obj_shade + 4 * (size_t)c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
                 HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth, flat && __float_as_uint(s3.z) != 0u, s2, __float_as_uint(s3.x), __float_as_uint(s3.y));
                 if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) n_warn++;                      // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
                 if constexpr (VIS) { if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) uv_warn++; }   // CheckUVCoordValid

@@ -940,6 +940,11 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     // request waits for the longest of its 64 rays.  Hence: trees outside LDS, requests of fewer than 32 rays.
     const bool ray_lanes = ray_lanes_ok && (s->shadow_rays >= 0 ? s->shadow_rays != 0 : (s->persistent_shadow < 0 && !s->use_lds && per_request < 32));
     // depth 0 without stored state (rt_kernels.h: primary_ray) unless a debug visualisation's kernel reads it (RT_HIP_RAYGEN=1: the stored form, for A/B runs)
+    {   // the object records in LDS when four workgroups' copies fit a CU beside everything else (<= 32 KB: 512 objects)
+        const size_t rec_bytes = s->obj_shade.bytes;
+        const char* e = getenv("RT_HIP_OBJ_SHADE_LDS");
+        rd.obj_shade_lds_bytes = (vis == RT_VIS_NONE && rec_bytes && rec_bytes <= 32 * 1024 && !(e && e[0] == '0')) ? (uint32_t)rec_bytes : 0u;
+    }
     rd.implicit_primary = (vis == RT_VIS_NONE && !getenv("RT_HIP_RAYGEN")) ? (s->use_lds && RT_PRIMARY_STORE ? 2u : 1u) : 0u;
     if (!rd.implicit_primary) { Timed t(r, RT_K_RAYGEN, st); hipLaunchKernelGGL(k_raygen, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd); }
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
@@ -947,7 +952,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           const bool prim = rd.implicit_primary && depth == 0;
           if (s->use_lds) hipLaunchKernelGGL(prim ? ks->closest_primary_lds : ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(prim ? ks->closest_primary : s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
-        { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), 0, st, s->dev, rd, depth); }
+        { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), rd.obj_shade_lds_bytes, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_tree_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_tree_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
           else if (ray_lanes) hipLaunchKernelGGL(ex ? ks->shadow_rays_exact : ks->shadow_rays, dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);

@@ -514,21 +514,21 @@ def test_untraced_shadow_rays_change_no_bit(cutoff, monkeypatch):
 
 @pytest.mark.parametrize("name", ["Testing", "CornellBox", "RgbSpheres", "MiniMesh", "Zoo"])
 def test_shortcuts_of_the_shading_kernel_change_no_bit(pairs, name, monkeypatch):
-    """Three ways the library saves k_shade work are knobs: the per-object records (RT_HIP_NO_OBJ_SHADE=1: walk object -> primitive and
-    object -> material -> textures instead), depth 0 without a ray-generation pass (RT_HIP_RAYGEN=1: k_raygen stores the camera
+    """The ways the library saves k_shade work are knobs: the per-object records (RT_HIP_NO_OBJ_SHADE=1: walk object -> primitive and
+    object -> material -> textures instead; RT_HIP_OBJ_SHADE_LDS=0: read them through the caches, not from a copy in LDS), depth 0 without a ray-generation pass (RT_HIP_RAYGEN=1: k_raygen stores the camera
     rays), the compact shadow requests (RT_HIP_FULL_REQUESTS=1).  Each moves the same numbers another way: the image sums and
     every counter of the statistics must be identical with any of them switched off."""
     sc, flat, _, _ = pairs(name)
     opt = RenderOptions(RenderWidth=80, RenderHeight=45, Passes=3, MaxBounceDepth=6, LightSampleCountHint=2, Seed=17)
-    def render(var=None):
-        if var: monkeypatch.setenv(var, "1")
+    def render(var=None, value="1"):
+        if var: monkeypatch.setenv(var, value)
         dev = rt.DeviceScene(flat)
         job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
         out = (job.ReadAccum()[0], job.UpdateStats()); job.Dispose(); dev.Dispose()
         if var: monkeypatch.delenv(var)
         return out
     ref, rst = render()
-    for var in ("RT_HIP_NO_OBJ_SHADE", "RT_HIP_RAYGEN", "RT_HIP_FULL_REQUESTS"):
-        got, st = render(var)
+    for var, value in (("RT_HIP_NO_OBJ_SHADE", "1"), ("RT_HIP_OBJ_SHADE_LDS", "0"), ("RT_HIP_RAYGEN", "1"), ("RT_HIP_FULL_REQUESTS", "1")):
+        got, st = render(var, value)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{var}: {(got != ref).sum()} sums differ"
         assert (st.RayCount, st.ShadowRays, st.MaterialScatterCount, st.SkyRays) == (rst.RayCount, rst.ShadowRays, rst.MaterialScatterCount, rst.SkyRays), var
