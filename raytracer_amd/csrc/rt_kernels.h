@@ -368,6 +368,9 @@ constexpr int SHADE_ITEMS = 8;
 #define RT_SHADE_MIN_WAVES 4
 #endif
 constexpr int SHADE_MIN_WAVES = RT_SHADE_MIN_WAVES;
+#ifndef RT_SHADE_DENSE
+#define RT_SHADE_DENSE 1
+#endif
 
 // RenderJob.UniqueColourFromMaterialHash, RenderJob.cs:317-328 (see rt_hip.h for the stand-in hash)
 RT_FN col3 material_hash_colour(uint32_t material, bool alternate) {
@@ -392,9 +395,17 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
     uint32_t sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0, n_warn = 0, uv_warn = 0;      // per thread: far below 2^32 (a thread shades a few thousand paths per launch)
-    __shared__ uint32_t wcnt[2][SHADE_ITEMS][BLOCK / 64];
-    __shared__ uint32_t bases[2];
+    __shared__ uint32_t wcnt[3][SHADE_ITEMS][BLOCK / 64];      // per item and wave: survivors, light requests, hits
+    __shared__ uint32_t bases[3];                              // first output position of the tile in either queue; hits in the tile
     constexpr uint32_t TILE = SHADE_ITEMS * BLOCK;
+    // Dense shading (trees in LDS, whose closest-hit kernel already finished the paths that missed): a third of the tile's positions
+    // are holes then, and shading position by position would leave a third of the lanes idle in a kernel that is bound by its
+    // arithmetic.  The hits' positions are written to a list in tile order, and the lanes shade list entry k = the k-th hit —
+    // whose output positions are base + k in both queues (every hit survives below the depth limit and asks for light if there
+    // is any: no Volumetric material in these variants) — in as many rounds as the hits need, not SHADE_ITEMS.  Same paths, same
+    // output order, same bits.
+    __shared__ unsigned short hit_list[TILE];
+    const bool dense = !VIS && !RT_HAS_MAT(C, RT_MAT_VOLUMETRIC) && rd.misses_end_in_closest && RT_SHADE_DENSE;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool can_survive = depth < rd.max_depth;
@@ -420,34 +431,57 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
               else if constexpr (RT_HAS_MAT(C, RT_MAT_VOLUMETRIC)) { if (hit) lit = lit && sc.materials[sc.obj_material[obj]].type != RT_MAT_VOLUMETRIC; }
           }
           const bool surv = hit && can_survive;
-          unsigned long long bs = __ballot(surv), bl = __ballot(lit);
-          if (lane == 0) { wcnt[0][item][wave] = (uint32_t)__popcll(bs); wcnt[1][item][wave] = (uint32_t)__popcll(bl); }
+          unsigned long long bs = __ballot(surv), bl = __ballot(lit), bh = __ballot(hit);
+          if (lane == 0) { wcnt[0][item][wave] = (uint32_t)__popcll(bs); wcnt[1][item][wave] = (uint32_t)__popcll(bl); wcnt[2][item][wave] = (uint32_t)__popcll(bh); }
           m_surv |= (surv ? 1u : 0u) << item; m_shad |= (lit ? 1u : 0u) << item; m_hit |= (hit ? 1u : 0u) << item;
       }
       __syncthreads();
-      if (threadIdx.x < 2) {
+      if (threadIdx.x < 3) {
           uint32_t tot = 0;
           for (int i = 0; i < SHADE_ITEMS; i++) for (int w = 0; w < BLOCK / 64; w++) tot += wcnt[threadIdx.x][i][w];
-          bases[threadIdx.x] = tot ? atomicAdd((threadIdx.x == 0 ? rd.qcount + depth + 1 : rd.sqcount + depth), tot) : 0u;
+          bases[threadIdx.x] = threadIdx.x == 2 ? tot : tot ? atomicAdd((threadIdx.x == 0 ? rd.qcount + depth + 1 : rd.sqcount + depth), tot) : 0u;
+      }
+      if (dense) {                                        // the tile's hits, in tile order
+          uint32_t row = 0;
+#pragma unroll
+          for (int item = 0; item < SHADE_ITEMS; item++) {
+              const bool hit = (m_hit >> item) & 1u;
+              uint32_t rank = row;
+              for (uint32_t w = 0; w < BLOCK / 64; w++) { const uint32_t ch = wcnt[2][item][w]; if (w < wave) rank += ch; row += ch; }
+              rank += (uint32_t)__popcll(__ballot(hit) & lt_mask);
+              if (hit) hit_list[rank] = (unsigned short)((uint32_t)item * BLOCK + threadIdx.x);
+          }
       }
       __syncthreads();
       uint32_t row_s = bases[0], row_l = bases[1];
+      const uint32_t n_hits = bases[2];
+      const int n_rounds = dense ? (int)((n_hits + BLOCK - 1) / BLOCK) : SHADE_ITEMS;
 #pragma unroll 1
-      for (int item = 0; item < SHADE_ITEMS; item++) {
-        const uint32_t j = tile + (uint32_t)item * BLOCK + threadIdx.x;
-        const bool survive = (m_surv >> item) & 1u, shadow = (m_shad >> item) & 1u;
-        // this path's output positions: rows before, waves before in the row, lanes before in the wave
-        uint32_t p0 = row_s, p1 = row_l;
-        for (uint32_t w = 0; w < BLOCK / 64; w++) {
-            uint32_t cs = wcnt[0][item][w], cl = wcnt[1][item][w];
-            if (w < wave) { p0 += cs; p1 += cl; }
-            row_s += cs; row_l += cl;
+      for (int item = 0; item < n_rounds; item++) {
+        uint32_t j, p0, p1; bool survive, shadow, valid;
+        if (dense) {
+            const uint32_t k = (uint32_t)item * BLOCK + threadIdx.x;
+            valid = k < n_hits;
+            j = tile + (valid ? (uint32_t)hit_list[k] : 0u);
+            survive = valid && can_survive; shadow = valid && sc.n_lights > 0;
+            p0 = row_s + k; p1 = row_l + k;
+        } else {
+            j = tile + (uint32_t)item * BLOCK + threadIdx.x;
+            survive = (m_surv >> item) & 1u; shadow = (m_shad >> item) & 1u;
+            // this path's output positions: rows before, waves before in the row, lanes before in the wave
+            p0 = row_s; p1 = row_l;
+            for (uint32_t w = 0; w < BLOCK / 64; w++) {
+                uint32_t cs = wcnt[0][item][w], cl = wcnt[1][item][w];
+                if (w < wave) { p0 += cs; p1 += cl; }
+                row_s += cs; row_l += cl;
+            }
+            p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
+            p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
+            // (a path whose ray hit nothing was finished by the closest-hit kernel — finish_miss — and its state is not even loaded here;
+            //  debug visualisations colour their misses themselves)
+            valid = j < n && (VIS || !rd.misses_end_in_closest || ((m_hit >> item) & 1u));
         }
-        p0 += (uint32_t)__popcll(__ballot(survive) & lt_mask);
-        p1 += (uint32_t)__popcll(__ballot(shadow) & lt_mask);
-        // (a path whose ray hit nothing was finished by the closest-hit kernel — finish_miss — and its state is not even loaded here;
-        //  debug visualisations colour their misses themselves)
-        if (j < n && (VIS || !rd.misses_end_in_closest || ((m_hit >> item) & 1u))) {
+        if (valid) {
             Ray r; col3 T, L; uint2 a3;
             if (primary) {                                                               // nothing stored for depth 0: the camera ray again (primary_ray)
                 if (rd.implicit_primary == 2u) { const float4 a0 = rd.st[cur][0][j], a1 = rd.st[cur][1][j]; r.o = mk3(a0.x, a0.y, a0.z); r.d = mk3(a0.w, a1.x, a1.y); }
