@@ -55,7 +55,7 @@ public static unsafe class RtHip
 {
 	private const string Lib = "rt_hip"; // librt_hip.so next to the assembly, or on LD_LIBRARY_PATH
 
-	public const uint AbiVersion = 3;            // RT_ABI_VERSION
+	public const uint AbiVersion = 4;            // RT_ABI_VERSION
 	public const uint NoHit      = 0xFFFFFFFFu;  // RT_NO_HIT
 	public const int  MaxDevices = 16;           // RT_MAX_DEVICES
 	public const uint RenderExactLightSampling = 1u;   // RT_RENDER_EXACT_LIGHT_SAMPLING
@@ -129,6 +129,7 @@ public static unsafe class RtHip
 	{
 		public uint NObjects; public uint NUnbounded; public uint NNodes; public uint BvhDepth; public uint TreeInLds; public uint LdsImageBytes; public uint BuiltOnDevice; public uint ObjectList;
 		public fixed byte Variant[16];
+		public uint WideNodes; public uint WideLevels; public int Device; public uint Reserved;
 	}
 
 	[StructLayout(LayoutKind.Sequential)]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef struct rt_scene  rt_scene;   /* opaque: flattened Scene + BVH on one device */
 typedef struct rt_render rt_render;  /* opaque: one RenderJob's device state */
@@ -384,6 +384,9 @@ typedef struct rt_scene_info {
     uint32_t built_on_device;         /* 1: built on the GPU (binned SAH, the default from 256 k bounded objects; RT_HIP_BVH=sah / =ploc / =device choose a device builder for any size), 0: SAH on the host (RT_HIP_BVH=host forces it) */
     uint32_t object_list;             /* 1: <= 16 bounded objects, traced as a list (every object for every ray, as the reference's any-hit does) instead of the tree */
     char     variant[16];             /* kernel variant specialised on the scene's content: "spheres", "mesh", "boxes", "generic" */
+    uint32_t wide_nodes, wide_levels; /* trees read through the caches (>= 1024 inner nodes; RT_HIP_WIDE=0/1 forces either): the 8-wide tree with quantised inner boxes made from the binary one — its node count and depth, 0 when the binary tree is traced */
+    int32_t  device;                  /* the HIP device the scene's tables live on (rt_scene_create's `device`, or HIP's current device then) */
+    uint32_t reserved;
 } rt_scene_info;
 int rt_scene_get_info(rt_scene* scene, rt_scene_info* out);
 

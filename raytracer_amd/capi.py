@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")     # RT_HIP_LIB: A/B a differently built library
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 RT_MAX_DEVICES = 16
 RENDER_EXACT_LIGHT_SAMPLING = 1
 RENDER_EXACT_OCCLUSION = 2
@@ -141,7 +141,7 @@ class KernelProfile(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("n_unbounded", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("tree_in_lds", C.c_uint32), ("lds_image_bytes", C.c_uint32), ("built_on_device", C.c_uint32), ("object_list", C.c_uint32),
-                ("variant", C.c_char * 16)]
+                ("variant", C.c_char * 16), ("wide_nodes", C.c_uint32), ("wide_levels", C.c_uint32), ("device", C.c_int32), ("reserved", C.c_uint32)]
 
 
 class Ray(C.Structure):

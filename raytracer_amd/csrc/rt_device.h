@@ -129,6 +129,10 @@ struct SceneDev {
     rt_skybox skybox;
     // small all-sphere scenes: a copy of the tree laid out for LDS (see LdsTree), null otherwise
     const uint4* lds_image;      uint32_t lds_image_bytes;   // q0[n_nodes] q1[n_nodes] q2[n_nodes] children[n_nodes] (int2, padded to 16 B) spheres[n_objects]
+    // big trees: the 8-wide tree with quantised inner boxes (rt_wide.h), null otherwise
+    const uint4* wide_nodes;     uint32_t wide_stride;       // bytes from one node record to the next
+    const char* wide_leaves;     uint32_t wide_leaf_stride;  // leaf-ordered records: the object's exact box, its id and code, then (wide_inline) a copy of its primitive
+    uint32_t wide_inline;        // the hittable type whose record follows every leaf's box (the tree holds that type only), or RT_NO_HIT
 };
 
 struct Ray { f3 o, d; };
@@ -469,7 +473,7 @@ RT_FN TravCount trav_count_zero() { TravCount c; c.nodes = 0; c.prims = 0; c.box
 // no reference arithmetic to reproduce here, BinaryBvhNode.FastTryHit has no box test — one fused multiply-add per plane,
 // t = plane * inv + addend: 6 packed FMAs per node instead of 6 packed subtracts and 6 packed multiplies.  The FMA form places a
 // plane with an absolute error of ~2^-23 |origin| (the rounding of the precomputed addend), which pad0 absorbs; reciprocals are
-// v_rcp_f32 (1 ulp is plenty here) clamped to +-1e30, so an axis-parallel ray gives +-huge, not inf - inf = NaN.
+// v_rcp_f32 (1 ulp is plenty here) clamped to +-1e12 / |d| (make_any_box), so an axis-parallel ray gives +-huge, not inf - inf = NaN.
 // o8x/y/z: 8 where the ray runs against the axis, else 0 — the byte offset that makes LdsTree's node layout hand out near/far planes.
 struct ClosestBox {
     f3 o, inv; uint32_t o8x, o8y, o8z;
@@ -526,6 +530,7 @@ RT_FN void planes_of(float4 q0, float4 q1, float4 q2, const Box& box, NodePlanes
     p.nz = gz ? mxz : mnz; p.fz = gz ? mnz : mxz;
 }
 struct HbmTree {
+    static constexpr bool wide = false;
     static constexpr bool vote = RT_TRAV_VOTE;
     static constexpr bool any_order = true;
     static constexpr bool list = true;       // scenes of a handful of objects are walked as a list (list_closest)
@@ -562,6 +567,7 @@ template <class C> RT_FN bool HbmTree::leaf_fast(const SceneDev& sc, uint32_t ob
 // (ds_read_i16 sign-extends it back), so push and pop are one LDS instruction each, no encoding.
 constexpr uint32_t LDS_NODE_BYTES = 80;
 struct LdsTree {
+    static constexpr bool wide = false;
     static constexpr bool any_order = false;
     static constexpr bool list = false;      // (the host never pairs the LDS tree with an object list: keeps these kernels' registers)
     static constexpr bool may_have_empty_child = false;      // rt_scene_create puts a tree in LDS only if it has two objects or more: every node is full
@@ -731,8 +737,13 @@ RT_FN bool list_any(const SceneDev& sc, const Ray& r, const AnyBox& box, float k
 }
 
 RT_FN float rcp_fast(float a);
-// the box test of a ray that sees every box larger by `pad` on every side
-RT_FN AnyBox make_any_box(const Ray& r, float pad) {
+// The box test of a ray that sees every box larger by `pad` on every side.  lim = ANY_INV_LIMIT / |d| bounds 1/d: a component
+// beyond it belongs to a ray that is parallel to that axis for every purpose (it moves less than 1e-12 of its length along it), and
+// its slab distances become +-(distance to the plane) * lim — on the far side at least pad * lim, beyond any hit — instead of
+// overflowing plane * inv in a scene 1e17 units across (where +-1e30, the limit of rounds 1 and 2, gave inf - inf: found by
+// tests/test_gpu_wide.py on the builders' geometric-spread case, two axis-parallel rays of 30 000 answered "not occluded").
+constexpr float ANY_INV_LIMIT = 1e12f;
+RT_FN AnyBox make_any_box(const Ray& r, float pad, float lim) {
     AnyBox b;
     const float dd[3] = {r.d.x, r.d.y, r.d.z}, oo[3] = {r.o.x, r.o.y, r.o.z};
     float in_[3], an_[3], af_[3]; uint32_t o8[3];
@@ -740,7 +751,7 @@ RT_FN AnyBox make_any_box(const Ray& r, float pad) {
     for (int i = 0; i < 3; i++) {
         const bool neg = __builtin_signbitf(dd[i]);
         const float sp = neg ? -pad : pad;
-        in_[i] = __builtin_fminf(__builtin_fmaxf(rcp_fast(dd[i]), -1e30f), 1e30f);
+        in_[i] = __builtin_fminf(__builtin_fmaxf(rcp_fast(dd[i]), -lim), lim);
         an_[i] = -(oo[i] + sp) * in_[i];                                                        // near plane: the min plane moved by -pad for a ray along +axis, the max plane moved by +pad otherwise
         af_[i] = -(oo[i] - sp) * in_[i];
         o8[i] = neg ? 8u : 0u;
@@ -773,10 +784,22 @@ RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax, float cap, in
         round = __builtin_fminf((__builtin_amdgcn_sqrtf((rm * rm) + (1.1e-6f * reach * reach)) - rm) * 1.02f, cap * rm);
     }
     again = mode == 0 && round > (sc.any_again * rm);
-    if (again) return make_any_box(r, 0.0f);
+    const float lim = ANY_INV_LIMIT * rcp_fast(len);
+    if (again) return make_any_box(r, 0.0f, lim);
     // + the rounding of the reported root (1e-6 reach), the reference's own margins, and the plane error of the FMA form
-    return make_any_box(r, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))));
+    return make_any_box(r, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))), lim);
 }
+
+// (rt_wide.h: the 8-wide tree with quantised inner boxes)
+struct WideTree;
+struct WideRay {              // what a node visit of the wide tree needs of the ray
+    f3 o, inv, pt;            // origin, 1/d clamped, pad * |1/d| per axis
+    uint32_t neg;             // bit a: the ray runs against axis a
+    uint32_t octinv;          // 7 - octant
+};
+template <class C> RT_FN void closest_wide(const SceneDev& sc, const WideTree& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt);
+template <class C> RT_FN bool any_wide(const SceneDev& sc, const WideTree& tree, const WideRay& wr, const Ray& r, float kMin, float kMax, TravCount& cnt);
+RT_FN WideRay wide_ray_any(const SceneDev& sc, const Ray& r, float kMax, float cap, int mode, bool& again);
 
 template <class C, class Tree>
 RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
@@ -787,7 +810,8 @@ RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMi
         float k; cnt.prims++;
         if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
     }
-    if (Tree::list && sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
+    if constexpr (Tree::wide) { if (sc.n_nodes) closest_wide<C>(sc, tree, r, kMin, best, cnt); }
+    else if (Tree::list && sc.n_list_pairs) list_closest<C>(sc, r, kMin, best, cnt);
     else if (sc.n_nodes) {
         const ClosestBox box = closest_box(r);
         Stk sp = stk_empty(); int cur = 0, pend = TRAV_DONE;
@@ -832,6 +856,13 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
     }
     if (!(Tree::list && sc.n_list_pairs) && !sc.n_nodes) return false;
     bool again;
+    if constexpr (Tree::wide) {
+        for (int look = 0;; look = 1) {                          // once, or twice (see any_box)
+            const auto wr = wide_ray_any(sc, r, kMax, cap, look, again);
+            if (any_wide<C>(sc, tree, wr, r, kMin, kMax, cnt)) return true;
+            if (!again) return false;
+        }
+    } else {
     AnyBox box = any_box(sc, r, kMax, cap, 0, again);
     for (;;) {                                                   // once, or twice (see any_box)
         if (Tree::list && sc.n_list_pairs) { if (list_any<C>(sc, r, box, kMin, kMax, cnt)) return true; }
@@ -851,6 +882,7 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
         }
         if (!again) return false;
         box = any_box(sc, r, kMax, cap, 1, again);
+    }
     }
 }
 

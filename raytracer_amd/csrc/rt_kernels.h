@@ -16,6 +16,7 @@
 // the kernels carry a throughput T and add T*c as they go: L = sum_k T_k c_k + T_n * terminal, T_{k+1} = T_k a_k.
 #pragma once
 #include "rt_device.h"
+#include "rt_wide.h"
 
 namespace rtd {
 
@@ -210,9 +211,14 @@ constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = RT_LDS_BLOCK_SHADOW;
 #define RT_LDS_BLOCK_RAYS 768
 #endif
 constexpr int LDS_BLOCK_RAYS = RT_LDS_BLOCK_RAYS;      // k_shadow_rays with the tree in LDS: 81 VGPRs let 6 waves/SIMD in, two blocks of 12 waves per CU
-template <bool LDS, int TB>
+// where a traversal kernel reads the tree from: the binary tree through the caches, the binary tree in LDS, the 8-wide tree through the caches
+enum : int { TREE_HBM = 0, TREE_LDS = 1, TREE_WIDE = 2 };
+template <int TREE, int TB>
 RT_FN auto make_tree(const SceneDev& sc) {
-    if constexpr (LDS) {
+    if constexpr (TREE == TREE_WIDE) {
+        WideTree t; t.stack = (uint2*)lds_stack + threadIdx.x; t.stride = TB;
+        return t;
+    } else if constexpr (TREE == TREE_LDS) {
         uint4* dst = (uint4*)lds_stack;
         const uint32_t n16 = sc.lds_image_bytes / 16;
         for (uint32_t i = threadIdx.x; i < n16; i += TB) dst[i] = sc.lds_image[i];
@@ -228,10 +234,11 @@ RT_FN auto make_tree(const SceneDev& sc) {
 // PRIMARY: the launch of depth 0 when the render keeps no stored state for it (rd.implicit_primary): the camera rays are made here
 // (primary_ray).  A kernel of its own so that the ray set-up does not cost the bounce launches registers (LDS tree: 57 -> 68 VGPRs
 // would leave room for one 1024-thread workgroup per CU instead of two); held to the same 8 waves per SIMD.
-template <class C, bool LDS, bool PRIMARY = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, LDS && PRIMARY ? 8 : 1) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, int TREE, bool PRIMARY = false>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK, TREE == TREE_LDS && PRIMARY ? 8 : 1) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = TREE == TREE_LDS;
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+    const auto tree = make_tree<TREE, TB>(sc);
     constexpr bool primary = PRIMARY;
     const uint32_t n = primary ? rd.n_paths : rd.qcount[depth];
     if (primary && blockIdx.x == 0 && threadIdx.x == 0) rd.qcount[0] = n;      // (k_shade reads it)
@@ -274,10 +281,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, LDS && PRIMAR
 #endif
 constexpr int REFILL_BELOW = RT_REFILL_BELOW, REFILL_MIN_TAKERS = RT_REFILL_MIN_TAKERS;
 
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, int TREE>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = TREE == TREE_LDS, WIDE = TREE == TREE_WIDE;
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+    const auto tree = make_tree<TREE, TB>(sc);
     const uint32_t n = rd.qcount[depth];
     const float4* g0 = rd.st[depth & 1][0]; const float4* g1 = rd.st[depth & 1][1]; const uint2* g3 = rd.ids[depth & 1];
     const float kMin = rd.k_min, kMax = rd.k_max;
@@ -294,13 +302,15 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
     TravCount cnt = trav_count_zero();
     bool active = false;                 // this lane holds a ray (possibly finished and waiting for its store)
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-    ClosestBox box = closest_box(r);
-    Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
+    ClosestBox box = closest_box(r);                                             // binary trees
     int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
+    f3 inv = mk3(0, 0, 1); WideRay wr = make_wide_ray(r, inv, 0.0f, 1.0f); WideCursor wc = wide_idle();      // the wide tree
+    Closest best; best.k = kMax; best.obj = RT_NO_HIT; best.aux = 0.0f;
+    auto lane_busy = [&]() { if constexpr (WIDE) return wide_busy(wc); else return cur != TRAV_DONE || pend != TRAV_DONE; };
     for (;;) {
         // ---- store / fetch for every lane that is not traversing
-        const unsigned long long idle = __ballot(cur == TRAV_DONE && pend == TRAV_DONE);
-        if (cur == TRAV_DONE && pend == TRAV_DONE) {
+        const unsigned long long idle = __ballot(!lane_busy());
+        if (!lane_busy()) {
             if (active) {
                 if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
                     if (!ray_has_nan(r)) {
@@ -332,26 +342,42 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) 
                         float k; cnt.prims++;
                         if (try_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
                     }
-                    if (sc.n_nodes) { box = closest_box(r); cur = 0; }
+                    if (sc.n_nodes) {
+                        if constexpr (WIDE) { inv = splat(1.0f) / r.d; wr = wide_ray_closest(sc, r, inv); wc = wide_start(wr); }
+                        else { box = closest_box(r); cur = 0; }
+                    }
                 }
             }
         }
         next = min(end, next + (uint32_t)__popcll(idle));
-        if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
+        if (!__any(lane_busy())) {
             if (!__any(active) && next >= end) break;     // nothing traversing, nothing to store, nothing to fetch
             continue;                                    // (rays that were finished at fetch time: store them, fetch again)
         }
         // ---- traverse until too few lanes are busy
         for (;;) {
-            if constexpr (decltype(tree)::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); } }
-            else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); }
-            if (pend != TRAV_DONE) {
-                uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
-                if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
-                leaf_advance(tree, cur, pend, sp);
+            if constexpr (WIDE) {
+#ifdef RT_WIDE_PROF
+                while (wide_vote(wc)) {
+                    if (RT_WIDE_PROF == 1) { const uint32_t nu = (uint32_t)__popcll(__ballot(wide_can_step(wc))); if (lane_id() == 0) { cnt.box_miss += 64u; cnt.prim_hit += nu; } }
+                    if (wide_can_step(wc)) cnt.nodes += wide_step(sc, tree, wr, kMin, best.k, wc);
+                }
+                if (RT_WIDE_PROF == 2) { const uint32_t nu = (uint32_t)__popcll(__ballot(wide_has_leaf(wc))); if (lane_id() == 0) { cnt.box_miss += 64u; cnt.prim_hit += nu; } }
+                if (wide_has_leaf(wc)) { TravCount t2 = trav_count_zero(); wide_leaf_closest<C>(sc, wide_take_leaf(wc, wr), r, inv, kMin, best, t2); cnt.nodes += t2.nodes; cnt.prims += t2.prims; }
+#else
+                while (wide_vote(wc)) if (wide_can_step(wc)) cnt.nodes += wide_step(sc, tree, wr, kMin, best.k, wc);
+                if (wide_has_leaf(wc)) wide_leaf_closest<C>(sc, wide_take_leaf(wc, wr), r, inv, kMin, best, cnt);
+#endif
+            } else {
+                if constexpr (decltype(tree)::vote) { while (step_vote(cur, pend)) if (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); } }
+                else while (cur >= 0) { cnt.nodes += 2; node_step<false>(sc, tree, box, kMin, best.k, cur, pend, sp, cnt.box_miss); }
+                if (pend != TRAV_DONE) {
+                    uint32_t obj = (uint32_t)~pend; float k; cnt.prims++;
+                    if (tree.template leaf_try<C>(sc, obj, r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
+                    leaf_advance(tree, cur, pend, sp);
+                }
             }
-            const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
-            const int n_busy = __popcll(__ballot(busy));
+            const int n_busy = __popcll(__ballot(lane_busy()));
             if (n_busy == 0) break;
             if (n_busy < REFILL_BELOW && next < end && 64 - n_busy >= REFILL_MIN_TAKERS) break;
         }
@@ -645,10 +671,11 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
 // waves per SIMD k_shadow is held to when the tree is read from HBM, per variant (none specialised: holding the Cornell variant to
 // 4 waves = 128 VGPRs instead of its 157 spills 22 of them and is slower, 56.9 vs 53.5 ms per batch)
 template <class C> struct ShadowTune { static constexpr int min_waves = 1; };
-template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LDS ? RT_SHADOW_LDS_WAVES : ShadowTune<C>::min_waves) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, int TREE, bool EXACT = false>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_LDS ? RT_SHADOW_LDS_WAVES : ShadowTune<C>::min_waves) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = TREE == TREE_LDS;
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+    const auto tree = make_tree<TREE, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
     const bool compact = requests_are_compact(rd, depth);
     uint32_t rays = 0;                                // per thread: at most a few thousand requests x rays x nodes
@@ -727,10 +754,11 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : LD
 // 127 VGPRs: one register more and it runs 3 waves instead of 4 (its shadow kernel 47.9 -> 56 ms per batch) — pinned, so that a
 // change elsewhere spills a register outside the loops instead of losing the wave.
 template <class C> struct ShadowRaysTune { static constexpr int min_waves = 1; };
-template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS ? (EXACT ? 1 : 6) : (EXACT ? 1 : ShadowRaysTune<C>::min_waves)) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
+template <class C, int TREE, bool EXACT = false>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_RAYS : BLOCK, TREE == TREE_LDS ? (EXACT ? 1 : 6) : (EXACT ? 1 : ShadowRaysTune<C>::min_waves)) k_shadow_rays(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = TREE == TREE_LDS;
     constexpr int TB = LDS ? LDS_BLOCK_RAYS : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+    const auto tree = make_tree<TREE, TB>(sc);
     __shared__ float contrib[3][TB];
     const uint32_t n = rd.sqcount[depth];
     const uint32_t n_lights = sc.n_lights, R = rd.light_samples * n_lights;
@@ -786,10 +814,12 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_RAYS : BLOCK, LDS ? (EXACT ? 1
 // waves per SIMD the kernel is held to, per variant (specialised next to the variants: 96 VGPRs instead of 99 for "spheres" is
 // 5 waves instead of 4 and 33.5 -> 36.8 Msamples/s on the 100 k spheres + 64 lights scene; the others would only spill)
 template <class C> struct ShadowPersistentTune { static constexpr int min_waves = 1; };
-template <class C, bool LDS, bool EXACT = false>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
-    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+template <class C> struct ShadowPersistentWideTune { static constexpr int min_waves = 1; };
+template <class C, int TREE, bool EXACT = false>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_WIDE ? ShadowPersistentWideTune<C>::min_waves : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool WIDE = TREE == TREE_WIDE;
+    constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<TREE, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
     const uint32_t n_lights = sc.n_lights, per_request = rd.light_samples * n_lights;
     const bool compact = requests_are_compact(rd, depth);
@@ -809,18 +839,20 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
     col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0);
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
     bool again = false;                  // the ray in flight gets a second look through grown boxes if it comes out unoccluded (any_box)
-    AnyBox box = make_any_box(r, 0.0f);
+    AnyBox box = make_any_box(r, 0.0f, 1.0f);                                          // binary trees
     uint32_t unused = 0;
     float kMin = 0, kMax = 0;
     int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
+    WideRay wr = make_wide_ray(r, mk3(0, 0, 1), 0.0f, 1.0f); WideCursor wc = wide_idle();      // the wide tree
+    auto lane_busy = [&]() { if constexpr (WIDE) return wide_busy(wc); else return cur != TRAV_DONE || pend != TRAV_DONE; };
     int spins = 0;
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
     for (;;) {
         bool fetched = false;
-        if (cur == TRAV_DONE && pend == TRAV_DONE) {
+        if (!lane_busy()) {
             if (flying && again && !occluded) {                                 // ---- unoccluded in the boxes as they are: look again in the grown ones
-                box = any_box(sc, r, kMax, rd.any_cap, 1, again);
-                cur = 0; sp = stk_empty();
+                if constexpr (WIDE) { wr = wide_ray_any(sc, r, kMax, rd.any_cap, 1, again); wc = wide_start(wr); }
+                else { box = any_box(sc, r, kMax, rd.any_cap, 1, again); cur = 0; sp = stk_empty(); }
             } else if (flying) {                                                // ---- account for the finished ray
                 flying = false;
                 const rt_light* l = sc.lights + li;
@@ -891,25 +923,36 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : Sh
                     }
                 }
                 again = false;
-                if (!occluded && sc.n_nodes) { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = stk_empty(); }
+                if (!occluded && sc.n_nodes) {
+                    if constexpr (WIDE) { wr = wide_ray_any(sc, r, kMax, rd.any_cap, 0, again); wc = wide_start(wr); }
+                    else { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = stk_empty(); }
+                }
             }
         }
         next += (uint32_t)__popcll(__ballot(fetched));
-        if (!__any(cur != TRAV_DONE || pend != TRAV_DONE)) {
+        if (!__any(lane_busy())) {
             if (!__any(flying) && next >= end) break;
             continue;                                                           // (rays decided without the tree: account, draw again)
         }
         // many lanes whose ray was decided without the tree (muted lights, the ground plane): serve them again before anybody traverses
-        if (RT_SKIP_MUTE_RAYS && spins < 3 && __popcll(__ballot(flying && cur == TRAV_DONE && pend == TRAV_DONE)) >= REFILL_MIN_TAKERS) { spins++; continue; }
+        if (RT_SKIP_MUTE_RAYS && spins < 3 && __popcll(__ballot(flying && !lane_busy())) >= REFILL_MIN_TAKERS) { spins++; continue; }
         spins = 0;
         for (;;) {
-            while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
-            if (pend != TRAV_DONE) {
-                prims++;
-                if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) { occluded = true; cur = TRAV_DONE; pend = TRAV_DONE; }
-                else leaf_advance(tree, cur, pend, sp);
+            if constexpr (WIDE) {
+                while (wide_vote(wc)) if (wide_can_step(wc)) nodes += wide_step(sc, tree, wr, kMin, kMax, wc);
+                if (wide_has_leaf(wc)) {
+                    prims++;
+                    if (wide_leaf_any<C>(sc, wide_take_leaf(wc, wr), r, kMin, kMax)) { occluded = true; wide_stop(wc); }
+                }
+            } else {
+                while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
+                if (pend != TRAV_DONE) {
+                    prims++;
+                    if (tree.template leaf_fast<C>(sc, (uint32_t)~pend, r, kMin, kMax)) { occluded = true; cur = TRAV_DONE; pend = TRAV_DONE; }
+                    else leaf_advance(tree, cur, pend, sp);
+                }
             }
-            const bool busy = cur != TRAV_DONE || pend != TRAV_DONE;
+            const bool busy = lane_busy();
             const int n_busy = __popcll(__ballot(busy));
             if (n_busy == 0) break;
             if (n_busy < REFILL_BELOW && __popcll(__ballot(!busy && (flying || next < end))) >= REFILL_MIN_TAKERS) break;
@@ -953,10 +996,10 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t 
 #endif
 
 // Parity hooks: one thread per caller-supplied ray, same device functions as the render kernels.
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
-    constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+template <class C, int TREE>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
+    constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+    const auto tree = make_tree<TREE, TB>(sc);
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         RngKey key = make_key(seed, (uint32_t)i, 0);
@@ -976,10 +1019,10 @@ __global__ void __launch_bounds__(LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_close
     }
 }
 
-template <class C, bool LDS>
-__global__ void __launch_bounds__(LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
-    constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
-    const auto tree = make_tree<LDS, TB>(sc);
+template <class C, int TREE>
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
+    constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<TREE, TB>(sc);
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         TravCount cnt = trav_count_zero();
@@ -1030,11 +1073,27 @@ struct KernelSet {
     void (*trace_any_lds)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
     void (*closest_primary)(SceneDev, RenderDev, uint32_t);        // depth 0 from the path number (k_closest<.., PRIMARY>)
     void (*closest_primary_lds)(SceneDev, RenderDev, uint32_t);
+    // the same kernels over the 8-wide tree (rt_wide.h), for trees that are read through the caches
+    struct Wide {
+        void (*closest)(SceneDev, RenderDev, uint32_t);
+        void (*closest_primary)(SceneDev, RenderDev, uint32_t);
+        void (*closest_persistent)(SceneDev, RenderDev, uint32_t);
+        void (*shadow)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_exact)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_rays)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_rays_exact)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_persistent)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_persistent_exact)(SceneDev, RenderDev, uint32_t);
+        void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
+        void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+    } wide;
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
                 k_closest_persistent<C, false>, k_shadow_persistent<C, false>, k_shadow<C, false, true>, k_shadow_persistent<C, false, true>, nullptr,
-                nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr, k_closest<C, false, true>, nullptr};
+                nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr, k_closest<C, false, true>, nullptr,
+                {k_closest<C, TREE_WIDE>, k_closest<C, TREE_WIDE, true>, k_closest_persistent<C, TREE_WIDE>, k_shadow<C, TREE_WIDE>, k_shadow<C, TREE_WIDE, true>, k_shadow_rays<C, TREE_WIDE>, k_shadow_rays<C, TREE_WIDE, true>,
+                 k_shadow_persistent<C, TREE_WIDE>, k_shadow_persistent<C, TREE_WIDE, true>, k_trace_closest<C, TREE_WIDE>, k_trace_any<C, TREE_WIDE>}};
     if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.closest_primary_lds = k_closest<C, true, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
     return k;
 }

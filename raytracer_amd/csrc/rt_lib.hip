@@ -23,6 +23,8 @@ namespace rtploc { int build(const rtbvh::Box* boxes, const uint32_t* object_ids
 namespace rtsah { int build(const rtbvh::Box* boxes, const uint32_t* object_ids, uint32_t n, void* d_nodes, uint32_t* max_depth, uint32_t* levels, std::string& err); }
 #define RT_KERNELS_COMMON
 #include "rt_kernels.h"
+namespace rtwide { int build(const void* d_nodes, uint32_t n_nodes, const rtd::SceneDev& tables, uint32_t inline_type, uint32_t node_stride, void** out_nodes, size_t* out_node_bytes,
+                             void** out_leaves, size_t* out_leaf_bytes, uint32_t* out_leaf_stride, uint32_t* out_n_wide, uint32_t* out_levels, std::string& err); }
 
 using namespace rtd;
 
@@ -79,7 +81,7 @@ constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 
 // every device buffer of a scene (X-macro: allocation, peer copy to a replica, pointer binding all walk the same list)
 #define RT_SCENE_BUFFERS(X) \
-    X(nodes) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
+    X(nodes) X(wide_nodes) X(wide_leaves) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
     X(axis0) X(axis1) X(axis2) X(disks) X(boxes) X(capsules) X(cylinders) X(media_rec) X(materials) X(textures) X(lights)
 
 struct rt_scene {
@@ -89,6 +91,8 @@ struct rt_scene {
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    bool use_wide = false;           // WideTree kernels (rt_wide.h): the 8-wide tree made from the binary one, for trees read through the caches
+    uint32_t wide_count = 0, wide_levels = 0;
     bool device_build = false;       // the tree was built by rt_lbvh.hip
     int shadow_rays = -1;            // one lane per shadow ray (k_shadow_rays): -1 = the library's rule, 0/1 = RT_HIP_SHADOW_RAYS
     bool has_phong = false;          // a Phong material somewhere: k_shadow_rays cannot fold its two sums
@@ -110,6 +114,7 @@ namespace {
 void bind_scene_pointers(rt_scene* s) {
     SceneDev& sd = s->dev;
     sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>();
+    sd.wide_nodes = s->wide_nodes.as<uint4>(); sd.wide_leaves = s->wide_leaves.as<char>();
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>();
     sd.obj_shade = s->obj_shade.bytes ? s->obj_shade.as<float4>() : nullptr;
     sd.unbounded = s->unbounded.as<uint32_t>(); sd.media = s->media.as<uint32_t>();
@@ -398,7 +403,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (device >= ndev) return fail(RT_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
-    if (int src = scratch_for_device(device)) return src;      // rt_trace_closest_noalloc's array on this device (once per device)
+    (void)scratch_for_device(device);      // rt_trace_closest_noalloc's array on this device (once per device).  Best effort: only that entry point needs it, and it resolves the address itself if this failed
 
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = ks;
@@ -579,6 +584,32 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             if ((rc = allow_big_lds(ks))) return rc;
         }
     }
+    // The 8-wide tree with quantised inner boxes (rt_wide.h, rt_wide.hip) for trees that are read through the caches: a third of the
+    // dependent node fetches per ray.  From 1024 inner nodes; RT_HIP_WIDE=1 / =0 forces it for any tree of two objects or more / never.
+    {
+        const char* e = getenv("RT_HIP_WIDE");
+        const bool want = e ? e[0] == '1' : n_nodes >= 1024;
+        sd.wide_inline = RT_NO_HIT;
+        if (want && !s->use_lds && !sd.n_list_pairs && boxes.size() >= 2 && n_nodes == boxes.size() - 1) {
+            uint32_t one_type = d->objects[box_obj[0]].type;
+            for (uint32_t obj : box_obj) if (d->objects[obj].type != one_type) { one_type = RT_NO_HIT; break; }
+            const uint32_t inline_type = (one_type == RT_HIT_SPHERE || one_type == RT_HIT_TRIANGLE || one_type == RT_HIT_QUAD) ? one_type : (uint32_t)RT_NO_HIT;
+            uint32_t stride = WIDE_NODE_BYTES;
+            if (const char* st = getenv("RT_HIP_WIDE_STRIDE")) stride = std::max<uint32_t>(WIDE_NODE_BYTES, ((uint32_t)atoi(st) + 15u) & ~15u);
+            void *wn = nullptr, *wl = nullptr; size_t wnb = 0, wlb = 0; uint32_t lstride = 0;
+            std::string err;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int brc = rtwide::build(s->nodes.p, (uint32_t)n_nodes, sd, inline_type, stride, &wn, &wnb, &wl, &wlb, &lstride, &s->wide_count, &s->wide_levels, err);
+            if (brc) return fail(brc == 2 ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "wide tree build: %s", err.c_str());
+            if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: wide tree of %u nodes (%zu MB) + %zu leaf records of %u B from %zu binary nodes: %.1f ms, %u levels\n", s->wide_count, wnb >> 20, boxes.size(), lstride, n_nodes,
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), s->wide_levels);
+            s->wide_nodes.p = wn; s->wide_nodes.bytes = wnb; s->wide_leaves.p = wl; s->wide_leaves.bytes = wlb;
+            sd.wide_nodes = (const uint4*)wn; sd.wide_stride = stride; sd.wide_leaves = (const char*)wl; sd.wide_leaf_stride = lstride; sd.wide_inline = inline_type;
+            s->use_wide = true;
+            s->stack_depth = std::max<uint32_t>(s->wide_levels + 1, 2);
+            if ((size_t)s->stack_depth * BLOCK * sizeof(uint2) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "wide tree of %u levels needs more LDS than one workgroup may use", s->wide_levels);
+        }
+    }
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 1014 Msamples/s with
     // persistent lanes, 100 k spheres no change, the 10-object Cornell box -11 %).  RT_HIP_PERSISTENT=0/1 overrides for A/B runs.
     { const char* e = getenv("RT_HIP_PERSISTENT_SHADOW"); s->persistent_shadow = e ? (e[0] == '1') : -1; }
@@ -596,6 +627,7 @@ int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
     out->n_objects = s->n_objects; out->n_unbounded = s->dev.n_unbounded; out->n_nodes = s->dev.n_nodes; out->bvh_depth = s->bvh_depth;
     out->tree_in_lds = s->use_lds ? 1u : 0u; out->lds_image_bytes = s->dev.lds_image_bytes;
     out->built_on_device = s->device_build ? 1u : 0u; out->object_list = s->dev.n_list_pairs ? 1u : 0u;
+    out->wide_nodes = s->use_wide ? s->wide_count : 0u; out->wide_levels = s->use_wide ? s->wide_levels : 0u; out->device = s->device;
     strncpy(out->variant, s->ks->name, sizeof(out->variant) - 1);
     return RT_OK;
 }
@@ -615,10 +647,10 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     *out = nullptr;
     DeviceGuard guard(device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", device);
-    if (int rc = scratch_for_device(device)) return rc;
+    (void)scratch_for_device(device);      // (best effort, as in rt_scene_create)
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
-    s->use_lds = src->use_lds; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
+    s->use_lds = src->use_lds; s->use_wide = src->use_wide; s->wide_count = src->wide_count; s->wide_levels = src->wide_levels; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
     s->n_objects = src->n_objects; s->n_lights = src->n_lights;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -641,7 +673,7 @@ static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t block
     uint64_t cap = (uint64_t)s->n_cu * blocks_per_cu;
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
-static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * sizeof(int); }
+static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * (s->use_wide ? sizeof(uint2) : sizeof(int)); }
 static inline size_t lds_tree_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
 static inline uint32_t lds_grid_for(const rt_scene* s, uint64_t work, int block, size_t lds_bytes) {
     uint64_t need = (work + block - 1) / block;
@@ -677,7 +709,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, f
     rt_ray* dr = s->trace_in.as<rt_ray>(); rt_hit* dh = s->trace_out.as<rt_hit>();
     HIP_TRY(hipMemcpy(dr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, dr, n, k_min, k_max, seed, dh);
-    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, n, k_min, k_max, seed, dh);
+    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_closest : s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, n, k_min, k_max, seed, dh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hits, dh, n * sizeof(rt_hit), hipMemcpyDeviceToHost));           // (null stream: ordered after the kernel, blocks until the copy is done)
     trace_release_large(s);
@@ -697,7 +729,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipMemcpy(d0, k_min, n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d1, k_max, n * sizeof(float), hipMemcpyHostToDevice));
     if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), 0, s->dev, dr, d0, d1, n, dout);
-    else hipLaunchKernelGGL(s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
+    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_any : s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, dout, n, hipMemcpyDeviceToHost));
     trace_release_large(s);
@@ -708,17 +740,17 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, uint64_t n, float 
     if (!s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_trace_closest_noalloc: null argument");
     if (n > RT_TRACE_NOALLOC_MAX_RAYS) return fail(RT_ERR_TOO_LARGE, "rt_trace_closest_noalloc: %llu rays, at most %u per call (use rt_trace_closest, which allocates)", (unsigned long long)n, (unsigned)RT_TRACE_NOALLOC_MAX_RAYS);
     if (!n) return RT_OK;
-    void* base = nullptr;
-    { std::lock_guard<std::mutex> lock(g_scratch_mutex); base = g_scratch[s->device]; }     // resolved by rt_scene_create on this device
-    if (!base) return fail(RT_ERR_HIP, "rt_trace_closest_noalloc: no scratch address for device %d", s->device);
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", s->device);
+    if (int rc = scratch_for_device(s->device)) return rc;      // normally resolved by rt_scene_create already; hipGetSymbolAddress allocates nothing
+    void* base = nullptr;
+    { std::lock_guard<std::mutex> lock(g_scratch_mutex); base = g_scratch[s->device]; }
     // [rays: MAX x rt_ray][hits: MAX x rt_hit]; every hit record of 0..n-1 is written by the kernel, nothing has to start at zero
     rt_ray* d_rays = (rt_ray*)base;
     rt_hit* d_hits = (rt_hit*)((unsigned char*)base + (size_t)RT_TRACE_NOALLOC_MAX_RAYS * sizeof(rt_ray));
     HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
-    else hipLaunchKernelGGL(s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
+    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_closest : s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost));       // (null stream: ordered after the kernel, blocks until the copy is done)
     return RT_OK;
@@ -951,12 +983,14 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
         { Timed t(r, RT_K_CLOSEST, st);
           const bool prim = rd.implicit_primary && depth == 0;
           if (s->use_lds) hipLaunchKernelGGL(prim ? ks->closest_primary_lds : ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
+          else if (s->use_wide) hipLaunchKernelGGL(prim ? ks->wide.closest_primary : s->persistent && depth > 0 ? ks->wide.closest_persistent : ks->wide.closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else hipLaunchKernelGGL(prim ? ks->closest_primary : s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), rd.obj_shade_lds_bytes, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_tree_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_tree_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
-          else if (ray_lanes) hipLaunchKernelGGL(ex ? ks->shadow_rays_exact : ks->shadow_rays, dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
+          else if (ray_lanes) hipLaunchKernelGGL(s->use_wide ? (ex ? ks->wide.shadow_rays_exact : ks->wide.shadow_rays) : (ex ? ks->shadow_rays_exact : ks->shadow_rays), dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          else if (s->use_wide) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->wide.shadow_persistent_exact : ks->wide.shadow_persistent) : (ex ? ks->wide.shadow_exact : ks->wide.shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on

@@ -48,15 +48,7 @@ class DeviceScene:
         self._lib = capi.load()
         self.handle = C.c_void_p()
         capi.check(self._lib.rt_scene_create(C.byref(self.flat.desc), device, C.byref(self.handle)))
-        if device < 0:
-            n = C.c_int(0)
-            device = 0
-            try:
-                import torch
-                device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-            except Exception:
-                pass
-        self._device = device
+        self._device = int(self.Info()["device"])          # the device rt_scene_create used (for -1: HIP's current device of this thread at that time)
 
     def DeviceOrdinal(self) -> int:
         """The HIP device the scene lives on (-1 at construction = HIP's current device at that time)."""
@@ -68,7 +60,7 @@ class DeviceScene:
         capi.check(self._lib.rt_scene_get_info(self.handle, C.byref(si)))
         return {"n_objects": si.n_objects, "n_unbounded": si.n_unbounded, "n_nodes": si.n_nodes, "bvh_depth": si.bvh_depth,
                 "tree_in_lds": bool(si.tree_in_lds), "lds_image_bytes": si.lds_image_bytes, "built_on_device": bool(si.built_on_device), "object_list": bool(si.object_list),
-                "variant": si.variant.decode()}
+                "variant": si.variant.decode(), "wide_nodes": si.wide_nodes, "wide_levels": si.wide_levels, "device": si.device}
 
     def TraceClosest(self, origins, directions, kMin=0.001, kMax=np.inf, seed=0):
         """RenderJob.TryFindClosestHit (RenderJob.cs:581-617) on a batch of rays -> structured array of rt_hit."""

@@ -7,7 +7,7 @@ name=$1; shift
 out=build_ab/$name; mkdir -p $out
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Wno-unused-function $*"
 pids=()
-for f in rt_lib rt_lbvh rt_ploc rt_sah rt_variant_spheres rt_variant_mesh rt_variant_boxes rt_variant_all; do
+for f in rt_lib rt_lbvh rt_ploc rt_sah rt_wide rt_variant_spheres rt_variant_mesh rt_variant_boxes rt_variant_all; do
   /opt/rocm/bin/hipcc $FLAGS -c -o $out/$f.o raytracer_amd/csrc/$f.hip & pids+=($!)
 done
 /opt/rocm/bin/hipcc $FLAGS -c -o $out/rt_bvh.o raytracer_amd/csrc/rt_bvh.cpp & pids+=($!)

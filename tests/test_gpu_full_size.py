@@ -208,7 +208,7 @@ def test_config5_device_built_trees_give_the_host_trees_hits(builder, monkeypatc
     o2, d2 = helpers.secondary_rays(flat, 100_000, rs)
     o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
     a, b = dev.TraceClosest(o, d, 0.001, np.inf, seed=3), host.TraceClosest(o, d, 0.001, np.inf, seed=3)
-    helpers.assert_closest_parity(a, b)
+    helpers.assert_closest_parity(a, b, flat=flat, rays=(o, d))
     kmin = np.full(len(o), 0.01, np.float32); kmax = rs.uniform(0.5, 60.0, len(o)).astype(np.float32)
     assert np.array_equal(dev.TraceAny(o, d, kmin, kmax), host.TraceAny(o, d, kmin, kmax))
     if builder == "sah":
