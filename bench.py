@@ -18,7 +18,14 @@ the scene, one host thread per device, sums gathered over xGMI) — what a C# ho
 RT_BENCH_ONE_GPU=1 maps every shard to device 0 (rehearsal on a 1-GPU box).
 
 Adds to the JSON line: "roofline" (dominant kernel, algorithmic flops / event-timed duration, SURVEY §8d cost
-model) and "cpu_baseline" (oracle/ — the C++ restatement of RenderInternal — on the host cores, rank 0, N=1).
+model) and "cpu_baseline" (oracle/ — the C++ restatement of RenderInternal — on the host cores, rank 0, N=1), and
+  "strong_scaling": ONE fixed job — config 2's 256 passes — split over the N ranks (256 / N passes each), timed end to end with the
+                    reduce and the resolve, the reduce's milliseconds beside it (BASELINE's configs 4 and 5 are jobs of that shape);
+  "value_exact":    (N = 1) the same workload with RT_RENDER_EXACT_LIGHT_SAMPLING | RT_RENDER_EXACT_OCCLUSION;
+  "configs":        (N = 1) short runs of configs 1, 3, 4 and 5 at full scene size and resolution (scripts/run_configs.py),
+                    each with Msamples/s, its dominant kernel, algorithmic flops / bytes, event-timed milliseconds and `frac`;
+  "world_size", "backend", "rccl_version": what the process group saw.
+--scaling strong makes the fixed 256-pass job the timed region itself (value = its Msamples/s, "scaling": "strong").
 """
 import argparse
 import json
@@ -63,7 +70,11 @@ def stats_dict(job):
     s = job.UpdateStats()
     return {"ray_count": s.RayCount, "shadow_rays": s.ShadowRays, "node_visits": s.NodeVisits, "prim_tests": s.PrimTests,
             "shadow_node_visits": s.ShadowNodeVisits, "shadow_prim_tests": s.ShadowPrimTests, "pixels": s.PixelsRendered,
-            "scatter": s.MaterialScatterCount, "limit": s.BounceLimitExceeded}
+            "scatter": s.MaterialScatterCount, "limit": s.BounceLimitExceeded, "depth_hist": list(s.RayDepthCounts)}
+
+
+def stats_delta(b, a):
+    return {k: [x - y for x, y in zip(b[k], a[k])] if isinstance(b[k], list) else b[k] - a[k] for k in a}
 
 
 def main():
@@ -77,6 +88,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-process", action="store_true", help="one process drives --gpus devices through the library's in-process sharding")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak: every GPU renders 256 passes per step; strong: ONE 256-pass job per step, split over the GPUs")
+    ap.add_argument("--no-configs", action="store_true", help="leave out the short runs of configs 1, 3, 4, 5")
+    ap.add_argument("--no-exact", action="store_true", help="leave out the exact-mode run of the same workload")
+    ap.add_argument("--no-strong", action="store_true", help="leave out the strong-scaling leg")
     args = ap.parse_args()
     PASSES_PER_STEP, PASSES_PER_BATCH = args.passes_per_step, args.passes_per_batch
 
@@ -109,10 +124,76 @@ def main():
     import raytracer_amd as rt
     from raytracer_amd.core import RenderOptions
 
+    backend = dist.get_backend() if world > 1 else "none"
+    try:
+        rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:      # noqa: BLE001 — a torch build without the binding
+        rccl = None
     scene = rt.BuiltinScenes.Testing()
     t0 = time.perf_counter()
     dev_scene = rt.DeviceScene(scene, local_rank)
     scene_upload_s = time.perf_counter() - t0
+    strong = args.scaling == "strong"
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def strong_job(reps, warm):
+        """ONE job of PASSES_PER_STEP passes, split over the ranks (rank r renders passes r, r + N, ...: 256 / N each), timed end to end:
+        zeroed sums -> passes -> reduce to rank 0 -> RGB24 on rank 0's host.  `reps` such jobs after `warm` untimed ones.  The batch size
+        is the library's choice for a call of that many passes (rt_render_opts.max_passes_per_call)."""
+        opt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=PASSES_PER_STEP, MaxBounceDepth=MAX_DEPTH, LightSampleCountHint=LIGHT_SAMPLES,
+                            PassesPerBatch=int(os.environ.get("RT_BENCH_STRONG_PPB", "0")))
+        job = rt.RenderJob(scene, opt, device=local_rank, rank=rank, world_size=world, device_scene=dev_scene)
+        first, n_mine, stride = rt.render_job.shard_passes(PASSES_PER_STEP, rank, world)
+        t_render = t_reduce = t_resolve = 0.0
+        t_all = 0.0
+        for i in range(warm + reps):
+            fence()
+            t0 = time.perf_counter()
+            if world > 1:
+                job._accum_tensor.zero_(); torch.cuda.synchronize()         # a new job starts from empty sums
+            job.RenderPasses(i * PASSES_PER_STEP + first, n_mine, stride)
+            t1 = time.perf_counter()
+            if world > 1:
+                job.ReduceToRoot()                                          # the one exchange step (RCCL reduce of W x H x 3 floats)
+            t2 = time.perf_counter()
+            if rank == 0:
+                job.UpdateImage(total_samples=PASSES_PER_STEP if world > 1 else None)
+            fence()
+            t3 = time.perf_counter()
+            if i >= warm:
+                t_all += t3 - t0; t_render += t1 - t0; t_reduce += t2 - t1; t_resolve += t3 - t2
+        job.Dispose()
+        t_all, t_render, t_reduce = max_over_ranks(t_all), max_over_ranks(t_render), max_over_ranks(t_reduce)
+        samples = WIDTH * HEIGHT * PASSES_PER_STEP * reps
+        return {"job": f"config 2 as one job: {WIDTH}x{HEIGHT} x {PASSES_PER_STEP} passes split over {world} GPU(s), sums zeroed -> passes -> reduce -> RGB24 on the host",
+                "jobs_timed": reps, "passes_per_gpu": n_mine, "seconds_per_job": t_all / reps, "value": samples / t_all / 1e6, "per_gpu": samples / t_all / 1e6 / world,
+                "unit": "Msamples/s", "render_ms": t_render / reps * 1e3, "reduce_ms": t_reduce / reps * 1e3, "resolve_and_barrier_ms": t_resolve / reps * 1e3}, samples, t_all
+
+    if strong:
+        sres, samples, dt = strong_job(args.steps, args.warmup)
+        out = {"metric": "Msamples/s", "value": sres["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Night Spheres (BuiltinScenes.Testing, seed 0x5EED) 1920x1080, depth 10, 2 light samples, "
+                                      f"one {PASSES_PER_STEP}-pass job per step split over the GPUs",
+                          "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"pass-sharded x{world}"},
+               "strong_scaling": sres, "world_size": world, "backend": backend, "rccl_version": rccl, "scene_info": dev_scene.Info()}
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     total_steps = args.warmup + args.steps
     opt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=total_steps * PASSES_PER_STEP * world, MaxBounceDepth=MAX_DEPTH,
                         LightSampleCountHint=LIGHT_SAMPLES, PassesPerBatch=PASSES_PER_BATCH)
@@ -120,11 +201,6 @@ def main():
 
     def step(i):     # pass p of this rank's step i: global pass index rank + world * (i * PPS + j)
         job.RenderPasses(rank + world * i * PASSES_PER_STEP, PASSES_PER_STEP, world)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -138,13 +214,9 @@ def main():
     if rank == 0:
         job.UpdateImage(total_samples=total_steps * PASSES_PER_STEP * world if world > 1 else None)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     s1 = stats_dict(job)
-    d = {k: s1[k] - s0[k] for k in s0}
+    d = stats_delta(s1, s0)
     if world > 1:
         t = torch.tensor([d["ray_count"], d["shadow_rays"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
@@ -160,6 +232,7 @@ def main():
                                f"{PASSES_PER_STEP} passes per step ({args.steps * PASSES_PER_STEP * world} spp timed)",
                    "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"pass-sharded x{world}"},
         "mrays_per_s": {"closest": rays_all / dt / 1e6, "shadow": shadow_all / dt / 1e6, "total": (rays_all + shadow_all) / dt / 1e6},
+        "world_size": world, "backend": backend, "rccl_version": rccl,
         "scene_upload_and_bvh_s": scene_upload_s,
         "ray_depth_counts": job.RenderStats.RayDepthCounts[:MAX_DEPTH + 1],
         "scene_info": dev_scene.Info(),
@@ -174,10 +247,10 @@ def main():
         prof = job.KernelProfile()
         job.SetProfiling(False)
         p1 = stats_dict(job)
-        pd = {k: p1[k] - p0[k] for k in p0}
+        pd = stats_delta(p1, p0)
         traffic = {}
         # PMC FETCH_SIZE/WRITE_SIZE of this workload (separate rocprofv3 passes: scripts/pmc_passes.sh, scripts/pmc_traffic.py)
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_traffic.json", "r01_traffic.json")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(q)), "")
         if tpath and PASSES_PER_BATCH == 64:
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tpath))["kernels"].items()}
         dominant = max(("closest", "shadow", "shade"), key=lambda k: prof[k]["total_ms"])
@@ -197,9 +270,15 @@ def main():
                             "this scene's tree lives in LDS, so they never reach HBM; `traffic` is what does (path state), from PMC counters."}
 
         def shade_roofline():
-            # k_shade moves path state: 64 B read per alive path (56 state + 8 hit), 56 B written per survivor, 48 B per shadow request, 16 B per finished path
-            alive, scat, fin = pd["ray_count"], pd["scatter"], pd["pixels"]
-            byts = 64 * alive + 56 * (scat - pd["limit"]) + 48 * (pd["shadow_rays"] // LIGHT_SAMPLES) + 16 * fin
+            # What k_shade moves today (rt_kernels.h: k_shade; Night Spheres: tree in LDS, so k_closest finished the misses — finish_miss — and left
+            # the depth-0 ray's 32 B; compact 16-B shadow requests below the depth limit):
+            #   8 B  per queue position (the counting phase reads every hit id)
+            #   32 B per depth-0 hit (the stored camera ray), 56 B per deeper hit (its state)
+            #   56 B per survivor (next state), 16 B per request of a survivor, 48 B per request of a path at the depth limit, 16 B per path ended there
+            alive, hits, lim = pd["ray_count"], pd["scatter"], pd["limit"]
+            hits0 = sum(pd["depth_hist"])                   # a path is in the histogram once it has hit something: the hits of depth 0
+            requests = pd["shadow_rays"] // LIGHT_SAMPLES   # one light
+            byts = 8 * alive + 32 * hits0 + 56 * (hits - hits0) + 56 * (hits - lim) + 16 * (requests - lim) + 48 * lim + 16 * lim
             sec, launches = prof["shade"]["total_ms"] / 1e3, max(prof["shade"]["launches"], 1)
             return {"kernel": "k_shade", "bound": "hbm", "achieved": byts / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / sec / 1e9 / HBM_PEAK_GBS,
                     "traffic": traffic.get("k_shade"), "launches": launches, "avg_launch_ms": prof["shade"]["total_ms"] / launches,
@@ -208,6 +287,44 @@ def main():
         out["roofline"] = shade_roofline() if dominant == "shade" else valu_roofline(dominant)
         out["roofline_others"] = [valu_roofline(k) for k in ("closest", "shadow") if k != dominant] + ([shade_roofline()] if dominant != "shade" else [])
         out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
+
+    job.Dispose()
+
+    if not args.no_strong:
+        out["strong_scaling"] = strong_job(2, 1)[0]
+
+    if rank == 0 and world == 1 and not args.no_exact:
+        # the same workload in the exact modes: the reference's correctly rounded light sampling, and occlusion answers equal to its every-object scan
+        eopt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=3 * PASSES_PER_STEP, MaxBounceDepth=MAX_DEPTH, LightSampleCountHint=LIGHT_SAMPLES,
+                             PassesPerBatch=PASSES_PER_BATCH, ExactLightSampling=True, ExactOcclusion=True)
+        ejob = rt.RenderJob(scene, eopt, device=local_rank, device_scene=dev_scene)
+        ejob.RenderPasses(0, PASSES_PER_BATCH, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ejob.RenderPasses(PASSES_PER_STEP, PASSES_PER_STEP, 1)
+        ejob.UpdateImage()
+        edt = time.perf_counter() - t0
+        ejob.Dispose()
+        out["value_exact"] = {"value": WIDTH * HEIGHT * PASSES_PER_STEP / edt / 1e6, "unit": "Msamples/s", "ms_per_step": edt * 1e3, "steps": 1,
+                              "flags": "RT_RENDER_EXACT_LIGHT_SAMPLING | RT_RENDER_EXACT_OCCLUSION", "vs_default": WIDTH * HEIGHT * PASSES_PER_STEP / edt / 1e6 / out["value"]}
+
+    if rank == 0 and world == 1 and not args.no_configs:
+        # BASELINE's other configs, short runs at full scene size and resolution (c2 is the line itself)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("run_configs", os.path.join(ROOT, "scripts", "run_configs.py"))
+        rc = importlib.util.module_from_spec(spec); spec.loader.exec_module(rc)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic_configs.json", "r02_traffic_configs.json")) if os.path.exists(q)), "")
+        ctraffic = json.load(open(tpath)) if tpath else {}
+        out["configs"] = []
+        for c in ("c1", "c3", "c4", "c5"):
+            r = rc.run_config(c, short=True, traffic=ctraffic)
+            rl = r["roofline"]
+            out["configs"].append({"config": c, "workload": r["workload"], "passes": r["passes"], "msamples_per_s": r["msamples_per_s"], "mrays_per_s": r["mrays_per_s"],
+                                   "dominant_kernel": rl["kernel"], "bound": rl["bound"], "frac": rl["frac"], "frac_valu": rl["frac_valu"], "frac_hbm_model": rl["frac_hbm_model"],
+                                   "frac_hbm_pmc": rl.get("frac_hbm_pmc"), "traffic": rl["traffic"], "launches": rl["launches"], "avg_launch_ms": rl["avg_launch_ms"],
+                                   "algorithmic_flops": rl["algorithmic_flops"], "algorithmic_bytes": rl["algorithmic_bytes"], "box_tests": rl["box_tests_V"], "prim_tests": rl["prim_tests_T"],
+                                   "kernel_ms_one_batch": r["kernel_ms_one_batch"], "scene_create_s": r["scene_create_s"],
+                                   "tree": {k: r["scene_info"][k] for k in ("n_objects", "n_nodes", "wide_nodes", "object_list", "variant", "built_on_device")}})
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
@@ -223,7 +340,6 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    job.Dispose()
     if world > 1:
         dist.destroy_process_group()
 
@@ -256,7 +372,7 @@ def single_process(args):
     job.UpdateImage()                                   # gathers the shards' sums onto devices[0] and resolves
     dt = time.perf_counter() - t0
     s1 = stats_dict(job)
-    d = {k: s1[k] - s0[k] for k in s0}
+    d = stats_delta(s1, s0)
     samples = WIDTH * HEIGHT * per_step * args.steps
     out = {"metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -265,8 +381,30 @@ def single_process(args):
                       "objects": len(scene.SceneObjects), "lights": len(scene.Lights), "parallelism": f"one process, pass-sharded over devices {devices} inside the library"},
            "mrays_per_s": {"closest": d["ray_count"] / dt / 1e6, "shadow": d["shadow_rays"] / dt / 1e6, "total": (d["ray_count"] + d["shadow_rays"]) / dt / 1e6},
            "scene_upload_and_bvh_s": scene_upload_s, "scene_info": dev_scene.Info()}
-    print(json.dumps(out))
     job.Dispose()
+    if not args.no_strong:
+        # ONE job of PASSES_PER_STEP passes behind one handle: the library splits every call's passes over the devices; the read gathers the
+        # shards' sums over xGMI onto devices[0] (rt_lib.hip: combine_shards) and resolves.  A new handle per job = sums that start at zero.
+        sopt = RenderOptions(RenderWidth=WIDTH, RenderHeight=HEIGHT, Passes=PASSES_PER_STEP, MaxBounceDepth=MAX_DEPTH, LightSampleCountHint=LIGHT_SAMPLES,
+                             PassesPerBatch=int(os.environ.get("RT_BENCH_STRONG_PPB", "0")))
+        sjob = rt.RenderJob(scene, sopt, device=devices[0], device_scene=dev_scene, devices=devices)
+        reps, t_render, t_read = 2, 0.0, 0.0
+        for i in range(1 + reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sjob.RenderPasses(i * PASSES_PER_STEP, PASSES_PER_STEP, 1)
+            t1 = time.perf_counter()
+            sjob.UpdateImage()
+            t2 = time.perf_counter()
+            if i >= 1:
+                t_render += t1 - t0; t_read += t2 - t1
+        sjob.Dispose()
+        ssamples = WIDTH * HEIGHT * PASSES_PER_STEP * reps
+        out["strong_scaling"] = {"job": f"config 2 as one job: {WIDTH}x{HEIGHT} x {PASSES_PER_STEP} passes split over {n} device(s) inside the library -> gather + add + RGB24 on the host",
+                                 "jobs_timed": reps, "passes_per_gpu": (PASSES_PER_STEP + n - 1) // n, "seconds_per_job": (t_render + t_read) / reps,
+                                 "value": ssamples / (t_render + t_read) / 1e6, "per_gpu": ssamples / (t_render + t_read) / 1e6 / n, "unit": "Msamples/s",
+                                 "render_ms": t_render / reps * 1e3, "gather_add_resolve_ms": t_read / reps * 1e3}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

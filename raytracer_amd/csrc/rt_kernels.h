@@ -977,9 +977,15 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum
     }
 }
 
-// n_devices > 1: another shard's colour sums into the combined buffer (rt_lib.hip: combine_shards)
-__global__ void __launch_bounds__(BLOCK) k_add(float* dst, const float* src, size_t n_values) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += (size_t)gridDim.x * BLOCK) dst[i] += src[i];
+// n_devices > 1: the shards' colour sums, added in shard order — ((s0 + s1) + s2) + ... whatever order the copies arrived in — into
+// the combined buffer (rt_lib.hip: combine_shards): every source is read once, the result written once
+struct ShardSums { const float* p[RT_MAX_DEVICES]; uint32_t n; };
+__global__ void __launch_bounds__(BLOCK) k_add_shards(float* dst, ShardSums src, size_t n_values) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_values; i += (size_t)gridDim.x * BLOCK) {
+        float s = src.p[0][i];
+        for (uint32_t g = 1; g < src.n; g++) s += src.p[g][i];
+        dst[i] = s;
+    }
 }
 
 // RenderJob.cs:646-654 ; Colour.Clamp01 / Sqrt / (Rgb24), Colour.cs:197-234
@@ -1041,6 +1047,10 @@ using CfgBoxes   = Cfg<pbit(RT_HIT_SPHERE) | pbit(RT_HIT_BOX) | pbit(RT_HIT_XY_P
                        pbit(RT_MAT_STANDARD) | pbit(RT_MAT_REFRACTIVE) | pbit(RT_MAT_EMISSIVE_REFRACTIVE), pbit(RT_TEX_SOLID),
                        pbit(RT_LIGHT_POINT) | pbit(RT_LIGHT_DIFFUSE_SPHERE)>;                       // Cornell box
 template <> struct ShadowPersistentTune<CfgSpheres> { static constexpr int min_waves = 5; };
+#ifndef RT_SPW_WAVES
+#define RT_SPW_WAVES 1
+#endif
+template <> struct ShadowPersistentWideTune<CfgSpheres> { static constexpr int min_waves = RT_SPW_WAVES; };
 template <> struct ShadowRaysTune<CfgBoxes> { static constexpr int min_waves = 4; };
 template <> struct ShadowPersistentTune<CfgBoxes> { static constexpr int min_waves = 4; };       // (128 VGPRs as it was; 129 with the check for lights that cannot matter)
 #ifndef RT_MESH_RAYS_WAVES

@@ -175,7 +175,9 @@ struct rt_render {
     // replicas this handle owns); its own slots / streams stay empty.  `combined` and `gather` live on shards[0]'s device.
     std::vector<rt_render*> shards;
     std::vector<rt_scene*> replicas;
-    DevBuf combined, gather;
+    DevBuf combined;
+    std::vector<std::unique_ptr<DevBuf>> gather;      // [G - 1] on shards[0]'s device: where shard g's sums arrive
+    std::vector<hipEvent_t> ev_gather;                // [G - 1], each created on its shard's device: that shard's copy is done
 };
 
 namespace {
@@ -761,6 +763,8 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, uint64_t n, float 
 // -------------------------------------------------------------------------------------------------
 // everything a render handle owns (also the clean-up of a half-built one: rt_render_create fails through it)
 static void release_render(rt_render* r) {
+    for (size_t g = 0; g < r->ev_gather.size(); g++) if (r->ev_gather[g]) { DeviceGuard dg(r->shards[g + 1]->device); (void)hipEventDestroy(r->ev_gather[g]); }
+    r->ev_gather.clear();
     for (rt_render* sh : r->shards) if (sh) { DeviceGuard g(sh->device); release_render(sh); }
     r->shards.clear();
     for (rt_scene* sc : r->replicas) if (sc) { DeviceGuard g(sc->device); delete sc; }
@@ -815,6 +819,10 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
     if (!ppb) {
         ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / n_pixels));
         if (o->max_passes_per_call) ppb = std::min(ppb, o->max_passes_per_call);
+        // A call shorter than two full batches is split in two, so that both batch slots work on it (one batch per slot leaves no
+        // other batch to overlap with).  Measured, Night Spheres 1080p, one job end to end (scripts/strong_batching.py): 64 passes as
+        // 1 x 64 3298, as 2 x 32 3431 Msamples/s; 32 passes 3084 -> 3163; 16 passes 2796 -> 2894 (steady state, 256 passes: 3590).
+        if (o->max_passes_per_call >= 16 && o->max_passes_per_call < 2 * ppb) ppb = (o->max_passes_per_call + 1) / 2;
     }
     if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
     // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob)
@@ -926,9 +934,16 @@ int rt_render_create(rt_scene* s, const rt_render_opts* o, rt_render** out) {
         if (int rc = create_single(sc, &so, &sh)) return rc;
         r->shards.push_back(sh);
     }
+    for (uint32_t g = 1; g < o->n_devices; g++) {         // (the event a shard's copy is recorded with lives on that shard's device)
+        DeviceGuard dg(r->shards[g]->device);
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        r->ev_gather.push_back(e);
+    }
     DeviceGuard guard(s->device);
     const size_t bytes = (size_t)o->width * o->height * 3 * sizeof(float);
-    HIP_TRY(r->combined.alloc(bytes)); HIP_TRY(r->gather.alloc(bytes));
+    HIP_TRY(r->combined.alloc(bytes));
+    for (uint32_t g = 1; g < o->n_devices; g++) { r->gather.emplace_back(new DevBuf()); HIP_TRY(r->gather.back()->alloc(bytes)); }
     r->rd = r->shards[0]->rd;
     *out = r.release();
     return RT_OK;
@@ -1056,18 +1071,28 @@ int rt_render_passes(rt_render* r, uint64_t first_pass, uint32_t n_passes, uint3
     return RT_OK;
 }
 
-// n_devices > 1: the shards' colour sums, added in shard order on shards[0]'s device -> r->combined.  Peer copies (xGMI) of
-// width*height*3 floats per shard (24.9 MB at 1080p, 99.5 MB at 4K), one add kernel each: the one exchange step of the path.
+// n_devices > 1: the shards' colour sums, added in shard order on shards[0]'s device -> r->combined: the one exchange step of the
+// path (width * height * 3 floats per shard: 24.9 MB at 1080p, 99.5 MB at 4K).  Every shard pushes its sums over its own xGMI link
+// into its own gather buffer, on its own stream — the G - 1 copies run side by side, not as a chain through one stream — and one
+// kernel on shards[0]'s stream, which waits for the G - 1 copy events, adds them: ((s0 + s1) + s2) + ..., the order of the shard
+// numbers whatever order the copies arrived in, so the image does not depend on timing.  (Not ncclReduce: its summation order is
+// the collective's to choose, and the image would then differ from run to run in the last bit; for a C# host it would also be a
+// second native dependency.  One process per GPU — raytracer_amd.RenderJob(rank, world_size), bench.py — does reduce with RCCL.)
 static int combine_shards(rt_render* r) {
     rt_render* r0 = r->shards[0];
     const size_t nv = (size_t)r->rd.n_pixels * 3, bytes = nv * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(r->combined.p, r0->accum, bytes, hipMemcpyDeviceToDevice, r0->stream));
+    ShardSums src{}; src.n = (uint32_t)r->shards.size(); src.p[0] = r0->accum;
     for (size_t g = 1; g < r->shards.size(); g++) {
         rt_render* sh = r->shards[g];
-        HIP_TRY(hipMemcpyPeerAsync(r->gather.p, r0->device, sh->accum, sh->device, bytes, r0->stream));
-        hipLaunchKernelGGL(k_add, dim3(grid_for(r0->scene, nv, 8)), dim3(BLOCK), 0, r0->stream, r->combined.as<float>(), r->gather.as<float>(), nv);
-        HIP_TRY(hipGetLastError());
+        DeviceGuard dg(sh->device);
+        HIP_TRY(hipMemcpyPeerAsync(r->gather[g - 1]->p, r0->device, sh->accum, sh->device, bytes, sh->stream));
+        HIP_TRY(hipEventRecord(r->ev_gather[g - 1], sh->stream));
+        src.p[g] = r->gather[g - 1]->as<float>();
     }
+    DeviceGuard guard(r0->device);
+    for (size_t g = 1; g < r->shards.size(); g++) HIP_TRY(hipStreamWaitEvent(r0->stream, r->ev_gather[g - 1], 0));
+    hipLaunchKernelGGL(k_add_shards, dim3(grid_for(r0->scene, nv, 8)), dim3(BLOCK), 0, r0->stream, r->combined.as<float>(), src, nv);
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 

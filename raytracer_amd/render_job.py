@@ -151,7 +151,9 @@ class RenderJob:
             self._accum_tensor = torch.zeros(H * W * 3, dtype=torch.float32, device=torch.device("cuda", self.device_scene.DeviceOrdinal()))
             torch.cuda.synchronize(self._accum_tensor.device)
             accum_ptr = self._accum_tensor.data_ptr()
-        self._opts = make_opts(renderOptions, device=-1, accum_device=accum_ptr, devices=devices)
+        # (a rank never asks for more than its own share of the job's passes in one call: the library sizes its batches by that)
+        self._opts = make_opts(renderOptions, device=-1, accum_device=accum_ptr, devices=devices,
+                               max_passes_per_call=shard_passes(renderOptions.Passes, rank, world_size)[1] if world_size > 1 else 0)
         self.handle = C.c_void_p()
         capi.check(self._lib.rt_render_create(self.device_scene.handle, C.byref(self._opts), C.byref(self.handle)))
         self.RenderStats = RenderStats(TotalTruePixels=W * H, TotalPasses=renderOptions.Passes)

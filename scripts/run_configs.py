@@ -13,14 +13,15 @@ Per config: Msamples/s and Mrays/s over `passes` passes (two batch slots in flig
     F_prim / B_prim = the scene's census-weighted mean over its tree primitives (sphere 28/16, triangle or quad 42/48, axis plane 14/24,
                       box 70/112, capsule 60/32, disk 42/48, cylinder 60/32), plane 12/24 for the unbounded InfinitePlane tests
     frac_valu = flops / time / 157.3 TFLOP/s (FP32 vector peak; the kernels are built -ffp-contract=off, so half of it is their ceiling)
-    frac_hbm_model = bytes / time / 8 TB/s — the §8d byte model counts every node and primitive fetch, cached or not
+    frac_hbm_model = bytes / time / 8 TB/s — the §8d byte model counts every node and primitive fetch, cached or not (8-wide trees:
+                     80 B per node visit spread over its child slots in use, 32 B per leaf box, see wide_model)
     frac_hbm_pmc   = ((FETCH_SIZE + WRITE_SIZE) * 1024 per launch + half the coalesced state reads) / time / 8 TB/s when --traffic names a
                      PMC file for this config (scripts/pmc_passes.sh with BENCH_CMD="python3 scripts/run_configs.py cN --short", then
                      scripts/pmc_traffic.py, which explains the calibration: gathers of 64-B node records are counted in full, coalesced
                      16-B-per-lane streams at half — so 16 B per bounce ray / 32 B per shadow request are added back here).  The counters
                      sit on the L2's memory side: Infinity Cache hits are included, it is an upper bound on HBM bytes.
-`roofline.frac` is frac_valu for scenes whose tree fits the caches (c1, c2, c3, c5: <= 6.4 MB of nodes) and frac_hbm_pmc (falling back
-to the model) for c4, whose 320 MB of nodes + 320 MB of triangles do not."""
+`roofline.frac` is frac_valu for scenes whose tree fits the caches (c1, c2, c3, c5: <= 6.4 MB of nodes); for c4 (88 MB of wide nodes + 480 MB
+of leaf records) it is the larger of frac_valu and frac_hbm_pmc (falling back to the model): whichever limit the kernel is nearer to."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -65,16 +66,93 @@ def snap(job):
     return {k: getattr(s, k) for k in STAT_KEYS}
 
 
-def roofline(which, d, ms, launches, n_unbounded, f_prim, b_prim):
+def wide_model(info, b_prim):
+    """Bytes per box test in the 8-wide tree (rt_wide.h): a node visit reads one 80-B record and tests every child slot in use, so an inner
+    box test costs 80 B x nodes / child slots in use (the tree's mean; a binary tree of n inner nodes has n + 1 leaves, and every wide node
+    but the root is somebody's child); a leaf's exact box is the 32 B in front of its primitive record."""
+    if not info.get("wide_nodes"):
+        return None
+    n_wide, n_leaves = info["wide_nodes"], info["n_nodes"] + 1
+    return {"bytes_per_inner_box_test": 80.0 * n_wide / max(n_wide - 1 + n_leaves, 1), "bytes_per_leaf_box_test": 32.0}
+
+
+def roofline(which, d, ms, launches, n_unbounded, f_prim, b_prim, wide=None):
     rays, V, T = (d["RayCount"], d["NodeVisits"], d["PrimTests"]) if which == "closest" else (d["ShadowRays"], d["ShadowNodeVisits"], d["ShadowPrimTests"])
     t_plane = min(rays * n_unbounded, T)                     # every ray asks every unbounded plane first (any-hit rays stop at the first hit)
     t_tree = T - t_plane
     flops = F_NODE * V + f_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][0] * t_plane + (60 * rays if which == "shadow" else 0)
-    byts = B_NODE * V + b_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][1] * t_plane
+    if wide:     # closest hit tests a leaf's own box (counted in V; a failed one is an AabbMiss, a passed one a primitive test); any-hit has no leaf box
+        v_leaf = min(V, t_tree + d["AabbMisses"]) if which == "closest" else 0
+        byts = wide["bytes_per_inner_box_test"] * (V - v_leaf) + wide["bytes_per_leaf_box_test"] * v_leaf + b_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][1] * t_plane
+    else:
+        byts = B_NODE * V + b_prim * t_tree + F_PRIM[capi.HIT_INFINITE_PLANE][1] * t_plane
     sec = ms / 1e3
     return {"kernel": "k_" + which, "rays": rays, "box_tests_V": V, "prim_tests_T": T, "launches": launches, "total_ms": ms, "avg_launch_ms": ms / max(launches, 1),
             "algorithmic_flops": flops, "algorithmic_bytes": byts, "tflops": flops / sec / 1e12 if sec else 0.0, "frac_valu": flops / sec / 1e12 / VALU_PEAK_TFLOPS if sec else 0.0,
             "model_gbs": byts / sec / 1e9 if sec else 0.0, "frac_hbm_model": byts / sec / 1e9 / HBM_PEAK_GBS if sec else 0.0}
+
+
+def run_config(c, short=False, traffic=None, exact=False):
+    """One config -> the dict that main() prints (bench.py's `configs` leg calls this too)."""
+    traffic = traffic or {}
+    label, mk, W, H, passes, depth, ls, ppb = CONFIGS[c]
+    if short:
+        passes = ppb
+    sc = mk()
+    t0 = time.perf_counter(); dev = rt.DeviceScene(sc); t_scene = time.perf_counter() - t0
+    n_unb, f_prim, b_prim = census(dev.flat)
+    opt = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, PassesPerBatch=ppb,
+                        ExactLightSampling=exact, ExactOcclusion=exact)
+    job = rt.RenderJob(sc, opt, device_scene=dev)
+    job.RenderPasses(10_000, ppb, 1)                      # warm-up batch
+    s0 = snap(job)
+    t0 = time.perf_counter(); job.RenderPasses(0, passes, 1); job.UpdateImage(); dt = time.perf_counter() - t0
+    s1 = snap(job)
+    d = {k: s1[k] - s0[k] for k in s0}
+    rays, sh = d["RayCount"], d["ShadowRays"]
+    info = dev.Info()
+    out = {"config": c, "workload": label, "passes": passes, "seconds": dt, "msamples_per_s": W * H * passes / dt / 1e6,
+           "mode": "exact light sampling + exact occlusion" if exact else "default",
+           "mrays_per_s": {"closest": rays / dt / 1e6, "shadow": sh / dt / 1e6},
+           "box_tests_per_closest_ray": d["NodeVisits"] / max(rays, 1), "prim_tests_per_closest_ray": d["PrimTests"] / max(rays, 1),
+           "box_tests_per_shadow_ray": d["ShadowNodeVisits"] / max(sh, 1), "prim_tests_per_shadow_ray": d["ShadowPrimTests"] / max(sh, 1),
+           "aabb_misses_per_closest_ray": d["AabbMisses"] / max(rays, 1), "scene_create_s": t_scene, "scene_info": info,
+           "prim_cost_model": {"unbounded_planes": n_unb, "flops_per_tree_prim_test": f_prim, "bytes_per_tree_prim_test": b_prim}}
+    # one batch with per-kernel event timing, and the counters of exactly that batch
+    job.SetProfiling(True); p0 = snap(job); job.RenderPasses(20_000, ppb, 1); prof = job.KernelProfile(); p1 = snap(job); job.SetProfiling(False)
+    pd = {k: p1[k] - p0[k] for k in p0}
+    out["kernel_ms_one_batch"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
+    wide = wide_model(info, b_prim)
+    rl = {w: roofline(w, pd, prof[w]["total_ms"], prof[w]["launches"], n_unb, f_prim, b_prim, wide) for w in ("closest", "shadow")}
+    dominant = max(rl, key=lambda w: rl[w]["total_ms"])
+    r = dict(rl[dominant])
+    tr = traffic.get(c, {}).get("kernels", {})
+    tnames = [k for k in tr if k.startswith("k_" + dominant)]
+    # a tree far larger than the caches (the node array alone beyond 64 MB, binary or wide): its fetches are what can bound the kernel
+    tree_bytes = info["wide_nodes"] * 80 if info["wide_nodes"] else info["n_nodes"] * 64
+    hbm_bound = tree_bytes > (64 << 20)
+    if tnames:
+        # the half of the coalesced path-state reads that FETCH_SIZE leaves out (k_closest: 2 float4 per ray; k_shadow: 3 float4 per request + its 16-B target)
+        n_light_rays = max(ls * max(len(sc.Lights), 1), 1)
+        left_out = 0.5 * (32 * r["rays"] if dominant == "closest" else 64 * r["rays"] / n_light_rays) / max(r["launches"], 1)
+        tot_bytes = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches_profiled"] for k in tnames); tot_launches = sum(tr[k]["launches_profiled"] for k in tnames)
+        per_launch = tot_bytes / max(tot_launches, 1) + left_out
+        r["traffic"] = per_launch
+        r["traffic_note"] = "L2 memory-side bytes per launch (Infinity Cache hits included): FETCH_SIZE + WRITE_SIZE, + the uncounted half of the coalesced state reads"
+        r["pmc_gbs"] = per_launch * r["launches"] / (r["total_ms"] / 1e3) / 1e9
+        r["frac_hbm_pmc"] = r["pmc_gbs"] / HBM_PEAK_GBS
+    else:
+        r["traffic"] = None
+    frac_hbm = r.get("frac_hbm_pmc", r["frac_hbm_model"])
+    if hbm_bound and frac_hbm >= r["frac_valu"]:
+        r.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", achieved=r.get("pmc_gbs", r["model_gbs"]), frac=frac_hbm,
+                 frac_uses="PMC FETCH_SIZE/WRITE_SIZE traffic" if tnames else "the byte model (counts cached node fetches too: an upper bound on HBM traffic)")
+    else:
+        r.update(bound="valu", peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", achieved=r["tflops"], frac=r["frac_valu"], frac_uses="algorithmic flops / FP32 vector peak")
+    out["roofline"] = r
+    out["roofline_other"] = rl["shadow" if dominant == "closest" else "closest"]
+    job.Dispose(); dev.Dispose()
+    return out
 
 
 def main():
@@ -85,56 +163,7 @@ def main():
         traffic = json.load(open(sys.argv[sys.argv.index("--traffic") + 1]))
         args = [a for a in args if not a.endswith(".json")]
     for c in (args or list(CONFIGS)):
-        label, mk, W, H, passes, depth, ls, ppb = CONFIGS[c]
-        if short:
-            passes = ppb
-        sc = mk()
-        t0 = time.perf_counter(); dev = rt.DeviceScene(sc); t_scene = time.perf_counter() - t0
-        n_unb, f_prim, b_prim = census(dev.flat)
-        opt = RenderOptions(RenderWidth=W, RenderHeight=H, Passes=passes, MaxBounceDepth=depth, LightSampleCountHint=ls, PassesPerBatch=ppb)
-        job = rt.RenderJob(sc, opt, device_scene=dev)
-        job.RenderPasses(10_000, ppb, 1)                      # warm-up batch
-        s0 = snap(job)
-        t0 = time.perf_counter(); job.RenderPasses(0, passes, 1); job.UpdateImage(); dt = time.perf_counter() - t0
-        s1 = snap(job)
-        d = {k: s1[k] - s0[k] for k in s0}
-        rays, sh = d["RayCount"], d["ShadowRays"]
-        out = {"config": c, "workload": label, "passes": passes, "seconds": dt, "msamples_per_s": W * H * passes / dt / 1e6,
-               "mrays_per_s": {"closest": rays / dt / 1e6, "shadow": sh / dt / 1e6},
-               "box_tests_per_closest_ray": d["NodeVisits"] / max(rays, 1), "prim_tests_per_closest_ray": d["PrimTests"] / max(rays, 1),
-               "box_tests_per_shadow_ray": d["ShadowNodeVisits"] / max(sh, 1), "prim_tests_per_shadow_ray": d["ShadowPrimTests"] / max(sh, 1),
-               "aabb_misses_per_closest_ray": d["AabbMisses"] / max(rays, 1), "scene_create_s": t_scene, "scene_info": dev.Info(),
-               "prim_cost_model": {"unbounded_planes": n_unb, "flops_per_tree_prim_test": f_prim, "bytes_per_tree_prim_test": b_prim}}
-        # one batch with per-kernel event timing, and the counters of exactly that batch
-        job.SetProfiling(True); p0 = snap(job); job.RenderPasses(20_000, ppb, 1); prof = job.KernelProfile(); p1 = snap(job); job.SetProfiling(False)
-        pd = {k: p1[k] - p0[k] for k in p0}
-        out["kernel_ms_one_batch"] = {k: round(v["total_ms"], 3) for k, v in prof.items()}
-        rl = {w: roofline(w, pd, prof[w]["total_ms"], prof[w]["launches"], n_unb, f_prim, b_prim) for w in ("closest", "shadow")}
-        dominant = max(rl, key=lambda w: rl[w]["total_ms"])
-        r = dict(rl[dominant])
-        tr = traffic.get(c, {}).get("kernels", {})
-        tname = next((k for k in tr if k.startswith("k_" + dominant)), None)
-        hbm_bound = dev.Info()["n_nodes"] * 64 > (64 << 20)        # the tree alone exceeds the 4 MB L2s x 8 and most of the 256 MB Infinity Cache's share
-        if tname:
-            # the half of the coalesced path-state reads that FETCH_SIZE leaves out (k_closest: 2 float4 per ray; k_shadow: 3 float4 per request + its 16-B target)
-            n_light_rays = max(ls * max(len(sc.Lights), 1), 1)
-            left_out = 0.5 * (32 * r["rays"] if dominant == "closest" else 64 * r["rays"] / n_light_rays) / max(r["launches"], 1)
-            per_launch = tr[tname]["hbm_bytes_per_launch"] + left_out
-            r["traffic"] = per_launch
-            r["traffic_note"] = "L2 memory-side bytes per launch (Infinity Cache hits included): FETCH_SIZE + WRITE_SIZE, + the uncounted half of the coalesced state reads"
-            r["pmc_gbs"] = per_launch * r["launches"] / (r["total_ms"] / 1e3) / 1e9
-            r["frac_hbm_pmc"] = r["pmc_gbs"] / HBM_PEAK_GBS
-        else:
-            r["traffic"] = None
-        if hbm_bound:
-            r.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", achieved=r.get("pmc_gbs", r["model_gbs"]), frac=r.get("frac_hbm_pmc", r["frac_hbm_model"]),
-                     frac_uses="PMC FETCH_SIZE/WRITE_SIZE traffic" if tname else "the SURVEY 8d byte model (counts cached node fetches too: an upper bound on HBM traffic)")
-        else:
-            r.update(bound="valu", peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", achieved=r["tflops"], frac=r["frac_valu"], frac_uses="algorithmic flops / FP32 vector peak")
-        out["roofline"] = r
-        out["roofline_other"] = rl["shadow" if dominant == "closest" else "closest"]
-        print(json.dumps(out), flush=True)
-        job.Dispose(); dev.Dispose()
+        print(json.dumps(run_config(c, short, traffic, exact="--exact" in sys.argv)), flush=True)
 
 
 if __name__ == "__main__":
