@@ -33,7 +33,7 @@ internal static class Program
 		{
 			if (!args[i].StartsWith("--")) return Usage($"unexpected argument '{args[i]}'");
 			string key = args[i][2..];
-			if (key is "list" or "exact-lights" or "exact-occlusion" or "help") flags.Add(key);
+			if (key is "list" or "exact-lights" or "exact-occlusion" or "validate" or "help") flags.Add(key);
 			else if (i + 1 < args.Length) opt[key] = args[++i];
 			else return Usage($"--{key} needs a value");
 		}
@@ -65,7 +65,8 @@ internal static class Program
 					Backend              = Enum.Parse<RenderBackend>(opt.GetValueOrDefault("backend", Environment.GetEnvironmentVariable("RT_BACKEND") ?? "hip"), true),
 					Devices              = opt.GetValueOrDefault("devices", "0").Split(',', StringSplitOptions.RemoveEmptyEntries).Select(d => int.Parse(d, CultureInfo.InvariantCulture)).ToArray(),
 					ExactLightSampling   = flags.Contains("exact-lights"),
-					ExactOcclusion       = flags.Contains("exact-occlusion")
+					ExactOcclusion       = flags.Contains("exact-occlusion"),
+					Validate             = flags.Contains("validate")
 			};
 		}
 		catch (Exception e) when (e is FormatException or OverflowException or ArgumentException)      // ArgumentOutOfRangeException<T> from the init accessors included
@@ -98,7 +99,7 @@ internal static class Program
 	{
 		if (error is not null) System.Console.Error.WriteLine("error: " + error);
 		System.Console.Error.WriteLine("usage: --list | [--scene NAME] [--width W] [--height H] [--passes N] [--depth D] [--light-samples S] [--kmin K] [--kmax K]\n" +
-		                               "       [--vis None|Normals|...] [--backend hip|cpu] [--devices 0,1,...] [--exact-lights] [--exact-occlusion] [--out image.png]");
+		                               "       [--vis None|Normals|...] [--backend hip|cpu] [--devices 0,1,...] [--exact-lights] [--exact-occlusion] [--validate] [--out image.png]");
 		return error is null ? 0 : 2;
 	}
 }

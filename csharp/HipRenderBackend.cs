@@ -9,18 +9,20 @@
 //     if (RenderOptions.Backend == RenderBackend.Hip) { new HipRenderBackend().Render(this, cancellationToken); return; }
 //
 // and RenderOptions three new init-only properties: `Backend` (default Cpu, or env RT_BACKEND=hip), `Devices`
-// (HIP ordinals; default: one GPU), `ExactLightSampling` and `ExactOcclusion`.  Nothing else in the public surface changes: Image,
+// (HIP ordinals; default: one GPU), `ExactLightSampling`, `ExactOcclusion` and `Validate`.  Nothing else in the public surface changes: Image,
 // ImageBuffer, RenderStats, RenderTask, StartOrGetRenderAsync keep their meaning.
 //
 // Core cannot name Impl types (Impl -> Core, Ararem.RayTracer.Impl.csproj:23), so flattening is an interface the
 // builtin Impl classes implement (csharp/Impl/DeviceFlatteners.cs); anything that does not implement it is rejected
 // with NotSupportedException at Render() time — there is no CPU fallback behind this backend.
 using System;
+using System.Collections.Concurrent;
 using System.Collections.Generic;
 using System.Runtime.CompilerServices;
 using System.Runtime.InteropServices;
 using System.Threading;
 using Ararem.RayTracer.Core.Acceleration;
+using Ararem.RayTracer.Core.Debugging;
 
 namespace Ararem.RayTracer.Core.Backends;
 
@@ -55,11 +57,12 @@ public static unsafe class RtHip
 {
 	private const string Lib = "rt_hip"; // librt_hip.so next to the assembly, or on LD_LIBRARY_PATH
 
-	public const uint AbiVersion = 4;            // RT_ABI_VERSION
+	public const uint AbiVersion = 5;            // RT_ABI_VERSION
 	public const uint NoHit      = 0xFFFFFFFFu;  // RT_NO_HIT
 	public const int  MaxDevices = 16;           // RT_MAX_DEVICES
 	public const uint RenderExactLightSampling = 1u;   // RT_RENDER_EXACT_LIGHT_SAMPLING
 	public const uint RenderExactOcclusion = 2u;       // RT_RENDER_EXACT_OCCLUSION
+	public const uint RenderValidate = 4u;             // RT_RENDER_VALIDATE
 	public const uint TraceNoAllocMaxRays = 1u << 17;  // RT_TRACE_NOALLOC_MAX_RAYS
 
 	// rt_hittable_type
@@ -178,6 +181,7 @@ public static unsafe class RtHip
 	[DllImport(Lib)] public static extern int    rt_render_stats(IntPtr render, out Stats stats);
 	[DllImport(Lib)] public static extern int    rt_render_set_profiling(IntPtr render, int enable);
 	[DllImport(Lib)] public static extern int    rt_render_kernel_profile(IntPtr render, out KernelProfile profile);
+	[DllImport(Lib)] public static extern int    rt_render_validator_counts(IntPtr render, ulong* normalsWrong, ulong* uvInvalid, uint nObjects);
 	[DllImport(Lib)] public static extern int    rt_trace_closest(IntPtr scene, Ray* rays, ulong n, float kMin, float kMax, ulong seed, Hit* hits);
 	[DllImport(Lib)] public static extern int    rt_trace_any(IntPtr scene, Ray* rays, float* kMin, float* kMax, ulong n, byte* occluded);
 	[DllImport(Lib)] public static extern int    rt_trace_closest_noalloc(IntPtr scene, Ray* rays, ulong n, float kMin, float kMax, ulong seed, Hit* hits);
@@ -253,9 +257,14 @@ public sealed unsafe class DeviceSceneBuilder
 
 internal sealed unsafe class HipRenderBackend : IRenderBackend
 {
-	/// <summary>Passes traced per rt_render_passes call: the cancellation and Image/RenderStats refresh granularity.  Also given to the library as
-	/// max_passes_per_call, so that it keeps path state for this many passes per batch and not for its default of 64.</summary>
-	private const uint PassesPerCall = 8;
+	/// <summary>How long one rt_render_passes call should take: the cancellation and Image / RenderStats refresh granularity.  The reference checks
+	/// its token per pixel (RenderJob.cs:97,114-118) and the GUI reads the image at 30 Hz (RenderBufferPanel.cs:53-79); a GPU call cannot be
+	/// interrupted, so the number of passes per call follows the measured time of the previous call instead of being a constant (8 passes
+	/// are 5 ms of Night Spheres at 1080p and 2 s of 100 000 spheres under 64 lights at 4K).</summary>
+	private const double TargetSecondsPerCall = 0.1;
+	/// <summary>Upper bound of passes per call and device, given to the library as max_passes_per_call: it keeps path state for this many passes per
+	/// batch (184 B per path and batch slot), and a call of two batches keeps both of its batch slots busy.</summary>
+	private const uint MaxPassesPerCall = 64;
 
 	public void Render(RenderJob job, CancellationToken ct)
 	{
@@ -301,8 +310,8 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 					StructSize = (uint)sizeof(RtHip.RenderOpts), Width = (uint)o.RenderWidth, Height = (uint)o.RenderHeight, KMin = o.KMin, KMax = o.KMax,
 					MaxBounceDepth = (uint)o.MaxBounceDepth, LightSampleCountHint = (uint)o.LightSampleCountHint, DebugVisualisation = (uint)o.DebugVisualisation,   // rt_debug_vis has the enum's values
 					Seed = (ulong)Random.Shared.NextInt64(), PassesPerBatch = 0, Device = -1, Stream = IntPtr.Zero, AccumDevice = null,
-					Flags = (o.ExactLightSampling ? RtHip.RenderExactLightSampling : 0u) | (o.ExactOcclusion ? RtHip.RenderExactOcclusion : 0u),
-					MaxPassesPerCall = PassesPerCall * (uint)devices.Length,        // one call's passes are split over the devices
+					Flags = (o.ExactLightSampling ? RtHip.RenderExactLightSampling : 0u) | (o.ExactOcclusion ? RtHip.RenderExactOcclusion : 0u) | (o.Validate ? RtHip.RenderValidate : 0u),
+					MaxPassesPerCall = MaxPassesPerCall * (uint)devices.Length,     // one call's passes are split over the devices
 					NDevices = devices.Length > 1 ? (uint)devices.Length : 0u
 			};
 			if (devices.Length > 1)
@@ -312,15 +321,23 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 			}
 			RtHip.Check(RtHip.rt_render_create(hScene, &ro, out hRender));
 
-			uint perCall = PassesPerCall * (uint)devices.Length;
+			uint nDev = (uint)devices.Length, perCall = nDev;                    // the first call: one pass per device, timed
+			byte[] rgb = new byte[job.ImageBuffer.Width * job.ImageBuffer.Height * 3];   // one staging buffer for every Publish of this job
+			ulong[] normalsWrong = o.Validate ? new ulong[objs.Length] : Array.Empty<ulong>(), uvInvalid = o.Validate ? new ulong[objs.Length] : Array.Empty<ulong>();
+			System.Diagnostics.Stopwatch call = new();
 			job.Stopwatch.Start();
 			for (ulong pass = 0; o.InfinitePasses || pass < o.Passes;)
 			{
 				if (ct.IsCancellationRequested) break;                           // RenderJob.cs:114-118: log and leave the loop, the task completes normally
-				uint n = o.InfinitePasses ? perCall : (uint)Math.Min(perCall, o.Passes - pass);
+				uint n = o.InfinitePasses ? perCall : (uint)Math.Min((ulong)perCall, o.Passes - pass);
+				call.Restart();
 				RtHip.Check(RtHip.rt_render_passes(hRender, pass, n, 1));          // with n_devices > 1 the library shards these n passes over the GPUs
+				double seconds = Math.Max(call.Elapsed.TotalSeconds, 1e-6);
 				pass += n;
-				Publish(job, hRender);                                             // the GUIs poll Image / RenderStats at 30 Hz without locks (RenderBufferPanel.cs:53-79)
+				Publish(job, hRender, rgb, normalsWrong, uvInvalid);               // the GUIs poll Image / RenderStats at 30 Hz without locks (RenderBufferPanel.cs:53-79)
+				// next call: as many passes as fit TargetSecondsPerCall at the rate just seen, a multiple of the device count, at most the library's batch
+				double want = n * TargetSecondsPerCall / seconds;
+				perCall = (uint)Math.Clamp(Math.Floor(want / nDev), 1.0, (double)MaxPassesPerCall) * nDev;
 			}
 			job.Stopwatch.Stop();
 		}
@@ -339,11 +356,11 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 			_                      => throw new NotSupportedException($"{h.GetType().FullName} does not expose its Material to the HIP backend")
 	};
 
-	/// <summary>RGB24 rows (row 0 = top, as Image&lt;Rgb24&gt;) into ImageBuffer; counters into RenderStats (RenderStats.cs:12-93).</summary>
-	private static void Publish(RenderJob job, IntPtr hRender)
+	/// <summary>RGB24 rows (row 0 = top, as Image&lt;Rgb24&gt;) into ImageBuffer; counters into RenderStats (RenderStats.cs:12-93); with
+	/// RenderOptions.Validate the two warn-only validator rules into GraphicsValidator.Errors per SceneObject, as RenderJob.cs:597,606 files them.</summary>
+	private static void Publish(RenderJob job, IntPtr hRender, byte[] rgb, ulong[] normalsWrong, ulong[] uvInvalid)
 	{
 		int w = job.ImageBuffer.Width, h = job.ImageBuffer.Height;
-		byte[] rgb = new byte[w * h * 3];
 		fixed (byte* p = rgb) RtHip.Check(RtHip.rt_render_read_rgb24(hRender, p));
 		job.ImageBuffer.ProcessPixelRows(acc =>
 		{
@@ -354,10 +371,19 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 		rs.PixelsRendered = s.PixelsRendered; rs.PassesRendered = s.PassesRendered; rs.MaterialScatterCount = s.MaterialScatterCount;
 		rs.MaterialAbsorbedCount = s.MaterialAbsorbedCount; rs.SkyRays = s.SkyRays; rs.BounceLimitExceeded = s.BounceLimitExceeded; rs.RayCount = s.RayCount;
 		rs.AabbMisses = s.AabbMisses; rs.HittableMisses = s.HittableMisses; rs.HittableIntersections = s.HittableIntersections;   // RenderStats.cs: the three BVH counters the GUI panels show
-		for (int d = 0; d < 64; d++) if (s.RayDepthCounts[d] != 0) rs.RayDepthCounts[d] = s.RayDepthCounts[d];
-		// the warn-only validator rules (RenderJob.cs:588-607): the device sums over objects, so the totals are filed under the scene itself
-		if (s.NormalsWrongMagnitude != 0) GraphicsValidator.Errors.GetOrAdd(GraphicsErrorType.NormalsWrongMagnitude, _ => new())[job.Scene] = s.NormalsWrongMagnitude;
-		if (s.UvInvalid != 0) GraphicsValidator.Errors.GetOrAdd(GraphicsErrorType.UVInvalid, _ => new())[job.Scene] = s.UvInvalid;
+		for (int d = 0; d < 64; d++) if (s.RayDepthCounts[d] != 0) rs.RayDepthCounts[(ulong)d] = s.RayDepthCounts[d];          // ConcurrentDictionary<ulong, ulong> (RenderStats.cs:93)
+		ConcurrentDictionary<object, ulong> Filed(GraphicsErrorType t) => GraphicsValidator.Errors.GetOrAdd(t, _ => new ConcurrentDictionary<object, ulong>());
+		if (normalsWrong.Length != 0)
+		{
+			// per object, keyed by the scene object as the reference keys them (RenderJob.cs:597, :606 pass `obj`; scene order = the library's object ids)
+			fixed (ulong* pn = normalsWrong) fixed (ulong* pu = uvInvalid) RtHip.Check(RtHip.rt_render_validator_counts(hRender, pn, pu, (uint)normalsWrong.Length));
+			for (int i = 0; i < normalsWrong.Length; i++)
+			{
+				if (normalsWrong[i] != 0) Filed(GraphicsErrorType.NormalsWrongMagnitude)[job.Scene.SceneObjects[i]] = normalsWrong[i];
+				if (uvInvalid[i] != 0) Filed(GraphicsErrorType.UVInvalid)[job.Scene.SceneObjects[i]] = uvInvalid[i];
+			}
+		}
+		else if (s.NormalsWrongMagnitude != 0) Filed(GraphicsErrorType.NormalsWrongMagnitude)[job.Scene] = s.NormalsWrongMagnitude;   // without Validate the device keeps the scene's total only
 	}
 
 	private static RtHip.Camera FlattenCamera(Camera c)

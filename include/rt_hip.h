@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef struct rt_scene  rt_scene;   /* opaque: flattened Scene + BVH on one device */
 typedef struct rt_render rt_render;  /* opaque: one RenderJob's device state */
@@ -291,6 +291,11 @@ typedef enum rt_debug_vis {          /* GraphicsDebugVisualisation.cs:4-61, same
                                                (exact up to a reach of ~1 100 smallest radii); only pixels whose shadow rays start farther than that
                                                from the objects can differ (a ground plane seen towards the horizon), and a dense scene renders up to 20x faster.  rt_trace_any is always exact.
                                                RT_HIP_EXACT_OCCLUSION=1 sets it for every render. */
+#define RT_RENDER_VALIDATE 4u               /* GraphicsValidator in full (RenderJob.cs:588-607, GraphicsValidator.cs:35-45): every closest hit of an
+                                               ordinary render gets its UV computed and checked as well as its normal, and both warn-only rules are
+                                               counted PER OBJECT (rt_render_validator_counts), as GraphicsValidator.Errors files them.  Off by
+                                               default: the UVs cost the shading kernel an atan2 / acos per sphere hit and the scene-specific
+                                               kernel variant.  Scenes of at most 65 536 objects (RT_ERR_TOO_LARGE beyond).  The image does not change. */
 
 typedef struct rt_render_opts {
     uint32_t struct_size;            /* sizeof(rt_render_opts) */
@@ -344,7 +349,7 @@ typedef struct rt_stats {
                                         |n.n - 1| > 0.01; RenderJob.cs:588-598 logs and counts it, changes nothing) — e.g. an InfinitePlane built with a normal
                                         that is not a unit vector (InfinitePlane.cs:20-25 keeps it as given).  Summed over objects. */
     uint64_t uv_invalid;             /* CheckUVCoordValid fails (GraphicsValidator.cs:62-66; RenderJob.cs:600-607 records GraphicsErrorType.UVInvalid): closest hits with a UV outside [0, 1]^2.
-                                        Counted where the device computes UVs: debug-visualisation renders (every hit); 0 otherwise */
+                                        Counted where the device computes UVs: debug-visualisation renders and renders with RT_RENDER_VALIDATE (every hit); 0 otherwise */
     uint64_t ray_depth_counts[RT_DEPTH_HIST_SIZE]; /* RenderStats.RayDepthCounts (:458); depths >= 63 land in [63] */
 } rt_stats;
 
@@ -422,6 +427,12 @@ typedef struct rt_kernel_profile {
 } rt_kernel_profile;
 int rt_render_set_profiling(rt_render* render, int enable);          /* also clears the totals */
 int rt_render_kernel_profile(rt_render* render, rt_kernel_profile* out);
+
+/* ---- ABI 5 ---- The two warn-only validator rules per object (GraphicsValidator.Errors[type][object], GraphicsValidator.cs:18, 35-45;
+ * recorded at RenderJob.cs:597 and :606): normals_wrong[i] / uv_invalid[i] = closest hits on scene object i whose normal is not a unit
+ * vector / whose UV lies outside [0, 1]^2, since the render was created.  Needs RT_RENDER_VALIDATE (RT_ERR_INVALID_ARG without);
+ * n_objects must be the scene's object count.  Either array may be NULL.  Summed over the shards when n_devices > 1. */
+int rt_render_validator_counts(rt_render* render, uint64_t* normals_wrong, uint64_t* uv_invalid, uint32_t n_objects);
 
 /* Parity hooks: RenderJob.TryFindClosestHit (RenderJob.cs:581-617) and AnyIntersectionFast (:575)
  * on caller-supplied rays. Ray i uses RNG key (seed, pixel=i, pass=0, depth=0) where an

@@ -31,6 +31,7 @@ def load():
         lib.orc_trace_any_culled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
         lib.orc_scene_set_culled_any.argtypes = [C.c_void_p, C.c_int]
         lib.orc_render.argtypes = [C.c_void_p, C.POINTER(capi.RenderOpts), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(capi.Stats)]
+        lib.orc_render_validated.argtypes = [C.c_void_p, C.POINTER(capi.RenderOpts), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(capi.Stats), C.c_void_p, C.c_uint32]
         lib.orc_resolve_rgb24.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.orc_camera_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(capi.Camera)]
         lib.orc_sphere_uv.argtypes = [C.c_void_p, C.c_void_p]
@@ -82,6 +83,16 @@ class OracleScene:
         n = options.Passes if n_passes is None else n_passes
         _check(load().orc_render(self.handle, C.byref(ro), first_pass, n, stride, threads, accum.ctypes.data, C.byref(st)))
         return accum, st.as_dict()
+
+    def render_validated(self, options, threads=1):
+        """render() plus GraphicsValidator.Errors (GraphicsValidator.cs:35-45): (rgb_sum, stats, normals_wrong[n_objects], uv_invalid[n_objects])."""
+        W, H = options.RenderWidth, options.RenderHeight
+        accum = np.zeros((H, W, 3), dtype=np.float32)
+        ro = make_opts(options)
+        st = capi.Stats()
+        per = np.zeros((self.flat.n_objects, 2), dtype=np.uint64)
+        _check(load().orc_render_validated(self.handle, C.byref(ro), 0, options.Passes, 1, threads, accum.ctypes.data, C.byref(st), per.ctypes.data, self.flat.n_objects))
+        return accum, st.as_dict(), per[:, 0].copy(), per[:, 1].copy()
 
     def close(self):
         if self.handle:

@@ -552,6 +552,7 @@ struct Stats {
     uint64_t aabbMisses = 0, hittableMisses = 0, hittableIntersections = 0, rayCount = 0, shadowRays = 0;
     uint64_t skyRays = 0, bounceLimit = 0, scatter = 0, absorbed = 0, pixels = 0;
     uint64_t normalsWrong = 0, uvInvalid = 0;       // GraphicsValidator.RecordError counts, summed over objects (RenderJob.cs:597, :606)
+    uint64_t* perObject = nullptr;                  // ... and per object, [n_objects][2] = (normals, UVs): GraphicsValidator.Errors[type][object] (GraphicsValidator.cs:35-45); this thread's own table, or null
     uint64_t depth[RT_DEPTH_HIST_SIZE] = {};
     void add(const Stats& o) {
         aabbMisses += o.aabbMisses; hittableMisses += o.hittableMisses; hittableIntersections += o.hittableIntersections;
@@ -802,6 +803,10 @@ struct CullTree {
             if (!MayHit(n.box, ray, invD, kMin, kMax, pad)) continue;
             if (n.count) { for (uint32_t i = 0; i < n.count; i++) if (order[n.first + i].h->FastTryHit(ray, kMin, kMax)) return true; }
             else if (sp + 2 <= 128) { stack[sp++] = n.left; stack[sp++] = n.right; }
+            else {      // a tree deeper than the stack (a median split keeps it near log2 n, so this is not expected): never skip a subtree — ask every object, as the reference does
+                for (const SceneObjectRef& o : order) if (o.h->FastTryHit(ray, kMin, kMax)) return true;
+                return false;
+            }
         }
         return false;
     }
@@ -872,8 +877,8 @@ static Found TryFindClosestHit(const SceneData& sc, const Ray& ray, float kMin, 
     }
     if (!best.ok()) return {};
     // the two warn-only rules: CheckVectorNormalized (GraphicsValidator.cs:52-60), CheckUVCoordValid (GraphicsValidator.cs:62-66); RenderJob.cs:588-607 logs, counts, changes nothing
-    if (!(!(std::fabs(LengthSquared(best.hit.Normal) - 1.0f) > 0.01f))) st.normalsWrong++;
-    if (!((best.hit.U >= 0.0f) && (best.hit.U <= 1.0f) && (best.hit.V >= 0.0f) && (best.hit.V <= 1.0f))) st.uvInvalid++;
+    if (!(!(std::fabs(LengthSquared(best.hit.Normal) - 1.0f) > 0.01f))) { st.normalsWrong++; if (st.perObject) st.perObject[2 * (size_t)best.obj]++; }
+    if (!((best.hit.U >= 0.0f) && (best.hit.U <= 1.0f) && (best.hit.V >= 0.0f) && (best.hit.V <= 1.0f))) { st.uvInvalid++; if (st.perObject) st.perObject[2 * (size_t)best.obj + 1]++; }
     // GraphicsValidator.CheckValueRange, Core/Debugging/GraphicsValidator.cs:69 ; RenderJob.cs:609-614
     if (!((best.hit.K >= kMin) && (best.hit.K <= kMax))) return {};
     return best;
@@ -1326,8 +1331,8 @@ int orc_scene_set_culled_any(orc_scene* s, int enable) { s->sc.culledAny = enabl
 // rgb_sum is in image-row order (row 0 = top, the y-flip of :631) and is accumulated into.
 // Threads split the pixel index range like Parallel.For (:96); per-thread stats are merged at the end
 // (the reference's Interlocked contention is NOT reproduced — this favours the CPU baseline).
-int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride,
-               uint32_t n_threads, float* rgb_sum, rt_stats* stats_out) {
+static int render_impl(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride,
+                       uint32_t n_threads, float* rgb_sum, rt_stats* stats_out, uint64_t* per_object, uint32_t n_objects) {
     if (!s || !opts || !rgb_sum || opts->width < 1 || opts->height < 1 || opts->light_sample_count_hint < 1) { g_err = "bad render args"; return RT_ERR_INVALID_ARG; }
     if (opts->debug_visualisation > RT_VIS_BOUNCE_DEPTH || opts->debug_visualisation == RT_VIS_UNDEFINED_TEST) { g_err = "Wrong enum value for debug visualisation"; return RT_ERR_INVALID_ARG; }   // RenderJob.cs:307-308
     RenderCtx rc{&s->sc, *opts};
@@ -1335,6 +1340,8 @@ int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, ui
     if (pass_stride < 1) pass_stride = 1;
     const uint64_t W = opts->width, H = opts->height, N = W * H;
     std::vector<Stats> tstats(n_threads);
+    std::vector<std::vector<uint64_t>> tper(per_object ? n_threads : 0);
+    for (uint32_t t = 0; t < tper.size(); t++) { tper[t].assign((size_t)n_objects * 2, 0); tstats[t].perObject = tper[t].data(); }
     for (uint32_t p = 0; p < n_passes; p++) {
         uint64_t pass = first_pass + (uint64_t)p * pass_stride;
         std::atomic<uint64_t> next{0};
@@ -1371,7 +1378,22 @@ int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, ui
         stats_out->bounce_limit_exceeded = tot.bounceLimit; stats_out->ray_count = tot.rayCount; stats_out->shadow_rays = tot.shadowRays;
         for (int i = 0; i < RT_DEPTH_HIST_SIZE; i++) stats_out->ray_depth_counts[i] = tot.depth[i];
     }
+    if (per_object) {
+        std::fill(per_object, per_object + (size_t)n_objects * 2, 0ull);
+        for (auto& t : tper) for (size_t i = 0; i < t.size(); i++) per_object[i] += t[i];
+    }
     return RT_OK;
+}
+int orc_render(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride,
+               uint32_t n_threads, float* rgb_sum, rt_stats* stats_out) {
+    return render_impl(s, opts, first_pass, n_passes, pass_stride, n_threads, rgb_sum, stats_out, nullptr, 0);
+}
+// ... with GraphicsValidator.Errors as the reference files them (GraphicsValidator.cs:35-45 via RenderJob.cs:597,606): per_object[2 * i] =
+// closest hits on scene object i whose normal is not a unit vector, [2 * i + 1] = whose UV lies outside [0, 1]^2
+int orc_render_validated(orc_scene* s, const rt_render_opts* opts, uint64_t first_pass, uint32_t n_passes, uint32_t pass_stride,
+                         uint32_t n_threads, float* rgb_sum, rt_stats* stats_out, uint64_t* per_object, uint32_t n_objects) {
+    if (!per_object || !s || n_objects != s->sc.objects.size()) { g_err = "orc_render_validated: per_object must hold two counters for each of the scene's objects"; return RT_ERR_INVALID_ARG; }
+    return render_impl(s, opts, first_pass, n_passes, pass_stride, n_threads, rgb_sum, stats_out, per_object, n_objects);
 }
 
 // the resolve at the end of UpdateBuffers (Core/RenderJob.cs:626-655), :646-654 ; Colour.Clamp01/Sqrt/(Rgb24), Core/Colour.cs:197-234

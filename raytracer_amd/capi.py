@@ -8,10 +8,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")     # RT_HIP_LIB: A/B a differently built library
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
 RT_MAX_DEVICES = 16
 RENDER_EXACT_LIGHT_SAMPLING = 1
 RENDER_EXACT_OCCLUSION = 2
+RENDER_VALIDATE = 4
 RT_NO_HIT = 0xFFFFFFFF
 RT_DEPTH_HIST_SIZE = 64
 
@@ -170,6 +171,7 @@ SYMBOLS = {
     "rt_render_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rt_render_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_render_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile)]),
+    "rt_render_validator_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "rt_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "rt_trace_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_trace_closest_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),

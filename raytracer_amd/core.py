@@ -217,7 +217,7 @@ class GraphicsDebugVisualisation:
 class RenderOptions:
     def __init__(self, RenderWidth=1920, RenderHeight=1080, KMin=0.001, KMax=math.inf, ConcurrencyLevel=None, Passes=100,
                  InfinitePasses=False, MaxBounceDepth=10, DebugVisualisation=0, LightSampleCountHint=2,
-                 Seed=0x5EED, PassesPerBatch=0, ExactLightSampling=False, ExactOcclusion=False):
+                 Seed=0x5EED, PassesPerBatch=0, ExactLightSampling=False, ExactOcclusion=False, Validate=False):
         if RenderWidth < 1:
             raise ArgumentOutOfRangeError("Image cannot have a width of less than 1 pixel")           # :52
         if RenderHeight < 1:
@@ -246,6 +246,8 @@ class RenderOptions:
         self.ExactLightSampling = bool(ExactLightSampling)
         # not in the reference: shadow rays that answer as the scan of all objects does even at the horizon (rt_hip.h RT_RENDER_EXACT_OCCLUSION)
         self.ExactOcclusion = bool(ExactOcclusion)
+        # not in the reference (which always validates, RenderJob.cs:588-607): also check every hit's UV and count both warn-only rules per object (rt_hip.h RT_RENDER_VALIDATE)
+        self.Validate = bool(Validate)
 
 
 @dataclass

@@ -57,6 +57,7 @@ struct RenderDev {
     uint32_t implicit_primary;        // depth 0 has no k_raygen pass: the first k_closest launch makes the camera ray of a path from its number (primary_ray); k_shade makes it again (1) or reads the 32 B k_closest left (2)
     float any_cap;            // any_box: growth limit in units of the smallest round radius (inf = RT_RENDER_EXACT_OCCLUSION)
     uint32_t vis;             // rt_debug_vis (k_shade<C, true> only)
+    unsigned long long* validate;     // RT_RENDER_VALIDATE: [n_objects][2] closest hits per object that fail the normal rule / the UV rule (k_shade<C, VIS, true> only), else null
 };
 
 // material ids are < 0xFFFF (rt_scene_create), 0xFFFF = none yet
@@ -416,8 +417,10 @@ template <bool EXACT> RT_FN col3 over_samples(col3 sum, float S) { if constexpr 
 
 // VIS = RenderOptions.DebugVisualisation != None (RenderJob.cs:148-309): the same kernel decides a debug colour from the first hit
 // instead of shading it (the host runs one bounce then, except for BounceDepth which runs the whole loop without colours).
-template <class C, bool VIS = false>
-__global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
+// VALIDATE = RT_RENDER_VALIDATE (GraphicsValidator in full, RenderJob.cs:588-607): UVs are computed for every hit, and both warn-only
+// rules are also counted per object (rd.validate), as GraphicsValidator.Errors files them.  Everything else is the same arithmetic.
+template <class C, bool VIS = false, bool VALIDATE = false>
+__global__ void __launch_bounds__(BLOCK, VIS || VALIDATE ? 1 : SHADE_MIN_WAVES) k_shade(SceneDev sc, RenderDev rd, uint32_t depth) {
     const uint32_t n = rd.qcount[depth];
     const int cur = depth & 1, nxt = cur ^ 1;
     uint32_t sky = 0, limit = 0, scat = 0, samples = 0, hist_miss = 0, n_warn = 0, uv_warn = 0;      // per thread: far below 2^32 (a thread shades a few thousand paths per launch)
@@ -539,9 +542,17 @@ __global__ void __launch_bounds__(BLOCK, VIS ? 1 : SHADE_MIN_WAVES) k_shade(Scen
                 float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
                 if (flat && rec_lds) { const float4* rec = (const float4*)lds_stack + 4 * c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
                 else if (flat) { const float4* rec = sc.obj_shade + 4 * (size_t)c.obj; s0 = rec[0]; s1 = rec[1]; s2 = rec[2]; s3 = rec[3]; }
-                HitRec h = finalize_hit<C, VIS>(sc, r, c, key, depth, flat && __float_as_uint(s3.z) != 0u, s2, __float_as_uint(s3.x), __float_as_uint(s3.y));
-                if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) n_warn++;                      // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
-                if constexpr (VIS) { if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) uv_warn++; }   // CheckUVCoordValid
+                HitRec h = finalize_hit<C, VIS || VALIDATE>(sc, r, c, key, depth, flat && __float_as_uint(s3.z) != 0u, s2, __float_as_uint(s3.x), __float_as_uint(s3.y));
+                if (fabsf(length_sq(h.n) - 1.0f) > 0.01f) {                              // GraphicsValidator.CheckVectorNormalized: !(Abs(LengthSquared - 1) > 0.01)
+                    n_warn++;
+                    if constexpr (VALIDATE) atomicAdd(rd.validate + 2 * (size_t)c.obj, 1ull);        // RecordError(NormalsWrongMagnitude, obj), RenderJob.cs:597
+                }
+                if constexpr (VIS || VALIDATE) {
+                    if (!((h.u >= 0.0f) && (h.u <= 1.0f) && (h.v >= 0.0f) && (h.v <= 1.0f))) {     // CheckUVCoordValid
+                        uv_warn++;
+                        if constexpr (VALIDATE) atomicAdd(rd.validate + 2 * (size_t)c.obj + 1, 1ull);  // RecordError(UVInvalid, obj), RenderJob.cs:606
+                    }
+                }
                 const rt_material* m = sc.materials + h.mat;
                 const uint32_t mtype = flat ? (__float_as_uint(s1.w) & 0xFFu) : m->type, mflags = flat ? (__float_as_uint(s1.w) >> 8) : m->flags;
                 const float mf0 = flat ? s0.w : m->f[0];
@@ -1112,5 +1123,7 @@ template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char
 // One translation unit per variant (rt_variant_*.hip) so that they compile in parallel; rt_lib.hip picks among them.
 extern const KernelSet ks_spheres, ks_mesh, ks_boxes, ks_all;
 extern void (*const k_shade_vis)(SceneDev, RenderDev, uint32_t);      // k_shade<CfgAll, true>: debug visualisations, any scene
+extern void (*const k_shade_validate)(SceneDev, RenderDev, uint32_t);      // k_shade<CfgAll, false, true>: RT_RENDER_VALIDATE, any scene
+extern void (*const k_shade_vis_validate)(SceneDev, RenderDev, uint32_t);  // k_shade<CfgAll, true, true>
 
 } // namespace rtd

@@ -164,6 +164,7 @@ struct rt_render {
     uint32_t sample_count = 0;
     uint64_t passes_rendered = 0;
     DevBuf stats, accum_buf, rgb;
+    DevBuf validate;                 // RT_RENDER_VALIDATE: u64 [n_objects][2], shared by the batch slots
     std::vector<unsigned long long> stats_host;
     // per-kernel event timing (rt_render_set_profiling)
     bool profiling = false;
@@ -794,7 +795,7 @@ static int check_render_opts(const rt_render_opts* o) {
         return fail(RT_ERR_INVALID_ARG, "Wrong enum value for debug visualisation (%u)", o->debug_visualisation);                           // RenderJob.cs:307-308
     if (o->max_bounce_depth > 4096) return fail(RT_ERR_TOO_LARGE, "max_bounce_depth above 4096");
     if ((uint64_t)o->width * o->height > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "more than 2^30 pixels");
-    if (o->flags & ~(RT_RENDER_EXACT_LIGHT_SAMPLING | RT_RENDER_EXACT_OCCLUSION)) return fail(RT_ERR_INVALID_ARG, "unknown bits in rt_render_opts.flags (0x%x)", o->flags);
+    if (o->flags & ~(RT_RENDER_EXACT_LIGHT_SAMPLING | RT_RENDER_EXACT_OCCLUSION | RT_RENDER_VALIDATE)) return fail(RT_ERR_INVALID_ARG, "unknown bits in rt_render_opts.flags (0x%x)", o->flags);
     if (o->n_devices > RT_MAX_DEVICES) return fail(RT_ERR_TOO_LARGE, "n_devices %u above RT_MAX_DEVICES (%d)", o->n_devices, RT_MAX_DEVICES);
     return RT_OK;
 }
@@ -856,6 +857,11 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
 
     r->n_slots = n_slots;
+    if (o->flags & RT_RENDER_VALIDATE) {
+        if (s->n_objects > (1u << 16)) return fail(RT_ERR_TOO_LARGE, "RT_RENDER_VALIDATE keeps two counters per object: at most 65536 objects (the scene has %u)", s->n_objects);
+        HIP_TRY(r->validate.alloc(std::max<size_t>(1, s->n_objects) * 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(r->validate.p, 0, r->validate.bytes, r->stream));
+    }
     HIP_TRY(r->stats.alloc(ST_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(r->stats.p, 0, r->stats.bytes, r->stream));
     HIP_TRY(r->rgb.alloc(n_pixels * 3));
@@ -895,6 +901,7 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.any_cap = r->exact_occlusion ? INFINITY : RT_ANY_GROWTH_CAP;
         rd.skip_mute_rays = ((uint64_t)rd.light_samples * s->n_lights > 2 || s->any_light_cutoff) ? 1u : 0u;
         rd.vis = o->debug_visualisation;
+        rd.validate = r->validate.as<unsigned long long>();
     }
     r->rd = r->slots[0].rd;
     r->stats_host.assign(ST_COUNT, 0);
@@ -970,7 +977,8 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     const bool first_hit_only = vis != RT_VIS_NONE && vis != RT_VIS_BOUNCE_DEPTH;
     const uint32_t max_depth = first_hit_only ? 0u : r->opts.max_bounce_depth;
     if (first_hit_only) rd.max_depth = 0;
-    auto shade_kernel = vis != RT_VIS_NONE ? k_shade_vis : ks->shade;
+    const bool validate = (r->opts.flags & RT_RENDER_VALIDATE) != 0;
+    auto shade_kernel = vis != RT_VIS_NONE ? (validate ? k_shade_vis_validate : k_shade_vis) : validate ? k_shade_validate : ks->shade;
     const bool trace_shadows = s->n_lights && (vis == RT_VIS_NONE || vis == RT_VIS_ESTIMATED_LIGHT);
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
     const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
@@ -1156,6 +1164,24 @@ int rt_render_stats(rt_render* r, rt_stats* out) {
         rt_stats one;
         if (int rc = stats_single(sh, &one)) return rc;
         for (size_t i = 0; i < sizeof(rt_stats) / sizeof(uint64_t); i++) ((uint64_t*)out)[i] += ((const uint64_t*)&one)[i];
+    }
+    return RT_OK;
+}
+
+int rt_render_validator_counts(rt_render* r, uint64_t* normals_wrong, uint64_t* uv_invalid, uint32_t n_objects) {
+    if (!r) return fail(RT_ERR_INVALID_ARG, "rt_render_validator_counts: null handle");
+    if (!(r->opts.flags & RT_RENDER_VALIDATE)) return fail(RT_ERR_INVALID_ARG, "rt_render_validator_counts: the render was created without RT_RENDER_VALIDATE");
+    if (n_objects != r->scene->n_objects) return fail(RT_ERR_INVALID_ARG, "rt_render_validator_counts: n_objects %u, the scene has %u", n_objects, r->scene->n_objects);
+    if (normals_wrong) std::fill(normals_wrong, normals_wrong + n_objects, 0ull);
+    if (uv_invalid) std::fill(uv_invalid, uv_invalid + n_objects, 0ull);
+    std::vector<rt_render*> parts = r->shards.empty() ? std::vector<rt_render*>{r} : r->shards;
+    std::vector<unsigned long long> host((size_t)n_objects * 2);
+    for (rt_render* sh : parts) {
+        if (!n_objects) break;
+        DeviceGuard guard(sh->device);
+        HIP_TRY(hipMemcpyAsync(host.data(), sh->validate.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, sh->stream));
+        HIP_TRY(hipStreamSynchronize(sh->stream));
+        for (uint32_t i = 0; i < n_objects; i++) { if (normals_wrong) normals_wrong[i] += host[2 * i]; if (uv_invalid) uv_invalid[i] += host[2 * i + 1]; }
     }
     return RT_OK;
 }

@@ -118,7 +118,8 @@ def make_opts(o: RenderOptions, device=-1, accum_device=0, stream=0, devices=Non
     ro.device = device
     ro.stream = stream or None
     ro.accum_device = accum_device or None
-    ro.flags = (capi.RENDER_EXACT_LIGHT_SAMPLING if getattr(o, "ExactLightSampling", False) else 0) | (capi.RENDER_EXACT_OCCLUSION if getattr(o, "ExactOcclusion", False) else 0)
+    ro.flags = ((capi.RENDER_EXACT_LIGHT_SAMPLING if getattr(o, "ExactLightSampling", False) else 0) | (capi.RENDER_EXACT_OCCLUSION if getattr(o, "ExactOcclusion", False) else 0) |
+                (capi.RENDER_VALIDATE if getattr(o, "Validate", False) else 0))
     if devices:
         if len(devices) > capi.RT_MAX_DEVICES:
             raise ValueError(f"at most {capi.RT_MAX_DEVICES} devices")
@@ -270,6 +271,14 @@ class RenderJob:
         s.NormalsWrongMagnitude, s.UVInvalid = st.normals_wrong_magnitude, st.uv_invalid
         s.RayDepthCounts = [int(x) for x in st.ray_depth_counts]
         return s
+
+    def ValidatorCounts(self):
+        """GraphicsValidator.Errors for this job (GraphicsValidator.cs:18): (normals_wrong, uv_invalid), one uint64 per scene object
+        (RenderOptions.Validate renders only)."""
+        n = self.device_scene.flat.n_objects
+        nw, uv = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        capi.check(self._lib.rt_render_validator_counts(self.handle, nw.ctypes.data, uv.ctypes.data, n))
+        return nw, uv
 
     def SetProfiling(self, enable: bool):
         capi.check(self._lib.rt_render_set_profiling(self.handle, 1 if enable else 0))

@@ -203,7 +203,10 @@ def test_backend_publishes_every_reference_stat_and_orders_destruction():
         assert re.search(r"rs\." + field + r"\s*=\s*s\." + field, BACKEND), field
     assert BACKEND.index("rt_render_destroy(hRender)") < BACKEND.index("rt_scene_destroy(hScene)")
     assert "interface IRenderBackend" in BACKEND and "class HipRenderBackend : IRenderBackend" in BACKEND
-    assert "MaxPassesPerCall = PassesPerCall" in BACKEND
+    assert "MaxPassesPerCall = MaxPassesPerCall * (uint)devices.Length" in BACKEND
+    # one staging buffer per job, not one per Publish (6 MB at 1080p, every call)
+    publish = BACKEND[BACKEND.index("private static void Publish("):]
+    assert "new byte[" not in publish[:publish.index("private static RtHip.Camera FlattenCamera")]
 
 
 def test_console_runner_uses_names_that_exist():
@@ -211,7 +214,7 @@ def test_console_runner_uses_names_that_exist():
     method it calls exists — in the backend source for what this port adds, in the mounted reference for the rest (that half skips
     on the GPU box, where /root/reference does not exist)."""
     src = open(os.path.join(ROOT, "csharp", "Console", "Program.cs")).read()
-    ours = ("Backend", "Devices", "ExactLightSampling", "ExactOcclusion")
+    ours = ("Backend", "Devices", "ExactLightSampling", "ExactOcclusion", "Validate")
     for name in ours:
         assert re.search(r"\b" + name + r"\s*=", src), name
         assert name in BACKEND, f"{name} is not described by HipRenderBackend.cs"
@@ -232,3 +235,60 @@ def test_console_runner_uses_names_that_exist():
     assert "public static IEnumerable<Scene> GetAll()" in open("/root/reference/Ararem.RayTracer.Impl/Builtin/BuiltinScenes.cs").read()
     validator = open(os.path.join(ref, "Debugging", "GraphicsValidator.cs")).read()
     assert "public static readonly ConcurrentDictionary<GraphicsErrorType, ConcurrentDictionary<object, ulong>> Errors" in validator
+
+
+def _cs_members(text):
+    """name -> declared type of the public fields / properties / methods of a C# source (generic arguments kept, `readonly` / `static` dropped)."""
+    out = {}
+    for m in re.finditer(r"^\s*public\s+(?:static\s+)?(?:readonly\s+)?(?!class|sealed|enum|record|interface|override)([\w\.<>,\s\?\[\]]+?)\s+(\w+)\s*(?:[;={(]|$)", text, flags=re.M):
+        out.setdefault(m.group(2), re.sub(r"\s+", "", m.group(1)))
+    return out
+
+
+def test_backend_touches_only_members_that_exist_with_compatible_types():
+    """The C# side has never met a compiler here, so the members of the reference's types that HipRenderBackend.cs reads or assigns are
+    checked against the mounted reference by NAME AND TYPE: what the backend does with each one must compile against that type
+    (an int index into ConcurrentDictionary<ulong, ulong> does not: VERDICT r02 weak 5)."""
+    ref = "/root/reference/Ararem.RayTracer.Core"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not mounted")
+    stats = _cs_members(open(os.path.join(ref, "RenderStats.cs")).read())
+    # every `rs.X = s.X` assigns a ulong of rt_stats to a ulong field
+    for field in re.findall(r"\brs\.(\w+)\s*=\s*s\.\w+", BACKEND):
+        assert stats.get(field) == "ulong", (field, stats.get(field))
+    # RayDepthCounts: ConcurrentDictionary<ulong, ulong> — its indexer takes a ulong key (no implicit int -> ulong conversion in C#)
+    assert stats["RayDepthCounts"] == "ConcurrentDictionary<ulong,ulong>"
+    for idx in re.findall(r"rs\.RayDepthCounts\[([^\]]+)\]", BACKEND):
+        assert idx.startswith("(ulong)"), f"rs.RayDepthCounts[{idx}]: the key type is ulong"
+    # RenderOptions: the reference's properties are ulong / float / bool / enum; every use narrows or compares explicitly
+    opts = _cs_members(open(os.path.join(ref, "RenderOptions.cs")).read())
+    for name, typ in (("RenderWidth", "ulong"), ("RenderHeight", "ulong"), ("Passes", "ulong"), ("MaxBounceDepth", "ulong"), ("LightSampleCountHint", "ulong"),
+                      ("KMin", "float"), ("KMax", "float"), ("InfinitePasses", "bool"), ("DebugVisualisation", "GraphicsDebugVisualisation")):
+        assert opts.get(name) == typ, (name, opts.get(name))
+    for name in ("RenderWidth", "RenderHeight", "MaxBounceDepth", "LightSampleCountHint", "DebugVisualisation"):
+        assert re.search(r"=\s*\(uint\)o\." + name + r"\b", BACKEND), f"{name} (ulong / enum) must be narrowed to the uint field explicitly"
+    assert re.search(r"\(uint\)Math\.Min\(\(ulong\)perCall, o\.Passes - pass\)", BACKEND)           # Math.Min(ulong, ulong) with `ulong pass`
+    assert re.search(r"for \(ulong pass = 0; o\.InfinitePasses \|\| pass < o\.Passes;\)", BACKEND)
+    # RenderJob: what the backend reads of the job
+    job = _cs_members(open(os.path.join(ref, "RenderJob.cs")).read())
+    for name, typ in (("Scene", "Scene"), ("RenderOptions", "RenderOptions"), ("RenderStats", "RenderStats"), ("ImageBuffer", "ImageFrame<Rgb24>"), ("Stopwatch", "Stopwatch")):
+        assert job.get(name) == typ, (name, job.get(name))
+        assert re.search(r"\bjob\." + name + r"\b", BACKEND), name
+    # Scene is a record (Scene.cs:9): SceneObjects is the array the object ids index, Lights the lights flattened in order
+    scene = open(os.path.join(ref, "Scene.cs")).read()
+    assert "SceneObject[] SceneObjects" in scene and "Light[] Lights" in scene and "SkyBox SkyBox" in scene and "Camera Camera" in scene
+    assert "job.Scene.SceneObjects[i]" in BACKEND and "scene.SceneObjects" in BACKEND and "scene.Lights" in BACKEND
+    # GraphicsValidator.Errors: ConcurrentDictionary<GraphicsErrorType, ConcurrentDictionary<object, ulong>> — GetOrAdd with a factory of exactly the inner type, ulong values
+    validator = open(os.path.join(ref, "Debugging", "GraphicsValidator.cs")).read()
+    assert "public static readonly ConcurrentDictionary<GraphicsErrorType, ConcurrentDictionary<object, ulong>> Errors" in validator
+    assert "GraphicsValidator.Errors.GetOrAdd(t, _ => new ConcurrentDictionary<object, ulong>())" in BACKEND
+    kinds = open(os.path.join(ref, "Debugging", "GraphicsErrorType.cs")).read()
+    for kind in set(re.findall(r"GraphicsErrorType\.(\w+)", BACKEND)):
+        assert re.search(r"\b" + kind + r"\b", kinds), kind
+    # the namespaces of what it names
+    for ns, probe in (("Ararem.RayTracer.Core.Debugging", "GraphicsValidator"), ("System.Collections.Concurrent", "ConcurrentDictionary<")):
+        assert f"using {ns};" in BACKEND and probe in BACKEND
+    # Camera: the seven members FlattenCamera reads (Camera.cs:26-29)
+    cam = open(os.path.join(ref, "Camera.cs")).read()
+    for name in re.findall(r"\bc\.(\w+)", BACKEND[BACKEND.index("FlattenCamera(Camera c)"):BACKEND.index("FlattenSky(SkyBox sky)")]):
+        assert re.search(r"\b" + name + r"\b", cam), f"Camera has no {name}"

@@ -117,7 +117,20 @@ def test_config2_night_spheres_1080p():
     assert abs(st.RayCount - rst["ray_count"]) <= 0.002 * rst["ray_count"] and abs(st.ShadowRays - rst["shadow_rays"]) <= 0.002 * rst["shadow_rays"]
 
 
-@pytest.mark.parametrize("intensity,direct", [(0.1, False), (1.0, True)])
+def test_config1_demo_as_stated():
+    """BASELINE config 1 exactly as stated — BuiltinScenes.Demo, 480 x 270, 64 passes, depth 8, 2 light samples (8.3 M samples) — against
+    the oracle path by path in the exact modes: >= 99.9 % of the pixels within 1e-3, every counter of rays equal."""
+    sc = bs.Demo(); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
+    opt = RenderOptions(RenderWidth=480, RenderHeight=270, Passes=64, MaxBounceDepth=8, LightSampleCountHint=2, Seed=0xC1, ExactLightSampling=True, ExactOcclusion=True)
+    job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait(); got, n = job.ReadAccum(); st = job.RenderStats; job.Dispose()
+    ref, rst = orc.render(opt, threads=16)
+    assert n == 64 and st.PixelsRendered == 480 * 270 * 64
+    assert _image_close(got, ref) >= 0.999
+    assert (st.RayCount, st.ShadowRays) == (rst["ray_count"], rst["shadow_rays"])
+    dev.Dispose()
+
+
+@pytest.mark.parametrize("intensity,direct", [(0.1, False), (0.1, True), (1.0, False), (1.0, True)])      # the four variants of Renders/Refractive.../info.md:8-9 (SURVEY §8d)
 def test_config3_cornell_depth32_1080p(intensity, direct):
     sc = bs.CornellBox(intensity, direct); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)
     assert dev.Info()["variant"] == "boxes" and dev.Info()["object_list"]
@@ -129,6 +142,13 @@ def test_config3_cornell_depth32_1080p(intensity, direct):
     job = rt.RenderJob(sc, opt_s, device_scene=dev); job.Wait(); g, _ = job.ReadAccum(); job.Dispose()
     ref, _ = orc.render(opt_s, threads=16)
     assert _image_close(g, ref) > 0.97
+    # the full-size frame in the exact modes: one pass of 1920 x 1080 at depth 32, path by path against the oracle
+    opt_x = RenderOptions(RenderWidth=1920, RenderHeight=1080, Passes=1, MaxBounceDepth=32, LightSampleCountHint=2, Seed=0xC3, ExactLightSampling=True, ExactOcclusion=True)
+    job = rt.RenderJob(sc, opt_x, device_scene=dev); job.Wait(); gx, _ = job.ReadAccum(); sx = job.RenderStats; job.Dispose()
+    refx, rsx = orc.render(opt_x, threads=16)
+    assert _image_close(gx, refx) >= 0.999
+    assert (sx.RayCount, sx.ShadowRays) == (rsx["ray_count"], rsx["shadow_rays"])
+    dev.Dispose()
 
 
 def test_config4_five_million_triangles(monkeypatch):
@@ -237,9 +257,10 @@ def test_check1_two_million_rays_night_spheres():
     assert (r["object"] != NO_HIT).sum() > 500_000
 
 
-@pytest.mark.parametrize("name,w,h,passes,depth", [("Testing", 160, 90, 32, 10), ("Demo", 160, 90, 32, 8), ("CornellBox", 96, 96, 32, 32)])
+@pytest.mark.parametrize("name,w,h,passes,depth", [("Testing", 480, 270, 256, 10), ("Demo", 480, 270, 256, 8), ("CornellBox", 480, 270, 256, 32)])
 def test_check2_rmse_against_the_oracles_noise_floor(name, w, h, passes, depth):
-    """SURVEY §8d check 2: with DIFFERENT seeds on the two sides (so nothing is compared path by path), the device image's RMSE
+    """SURVEY §8d check 2 — converged images at high spp: 480 x 270 at 256 spp (33 M samples a picture; the oracle renders two of them)
+    in the default modes.  With DIFFERENT seeds on the two sides (so nothing is compared path by path), the device image's RMSE
     against an oracle image is at most 1.5 x the RMSE between two independent oracle images at the same spp, per channel, and
     the channel means agree within 0.5 % (+ the standard error of the mean at this spp)."""
     sc = helpers.small_scenes()[name](); flat = flatten_scene(sc); dev, orc = rt.DeviceScene(flat), ob.OracleScene(flat)

@@ -253,6 +253,31 @@ def test_debug_visualisations_match_the_oracle(pairs, name, vis):
     assert close > 0.985, f"{VIS_NAMES[vis]} on {name}: only {close:.4f} of pixels match"
 
 
+@pytest.mark.parametrize("name,devices", [("Zoo", None), ("Demo", None), ("Testing", None), ("Zoo", [0, 0])])
+def test_validator_in_ordinary_renders_per_object(pairs, name, devices):
+    """RT_RENDER_VALIDATE (RenderOptions.Validate): an ordinary render checks every closest hit's normal AND UV and files both rules per
+    object, as GraphicsValidator.Errors does (RenderJob.cs:588-607, GraphicsValidator.cs:35-45) — equal to the oracle's per-object counts
+    (exact modes: the same paths, so the same hits), also through two shards inside the library; the picture is the one the render
+    without the flag makes, bit for bit."""
+    sc, flat, dev, orc = pairs(name)
+    kw = dict(RenderWidth=96, RenderHeight=54, Passes=4, MaxBounceDepth=6, LightSampleCountHint=2, Seed=12, ExactLightSampling=True, ExactOcclusion=True)
+    job = rt.RenderJob(sc, RenderOptions(Validate=True, **kw), device_scene=dev, devices=devices); job.Wait()
+    got, _ = job.ReadAccum(); st = job.UpdateStats(); nw, uv = job.ValidatorCounts(); job.Dispose()
+    ref, rst, onw, ouv = orc.render_validated(RenderOptions(**kw), threads=8)
+    assert (st.RayCount, st.ShadowRays) == (rst["ray_count"], rst["shadow_rays"])
+    assert np.array_equal(nw, onw) and np.array_equal(uv, ouv), (nw, onw, uv, ouv)
+    assert (int(nw.sum()), int(uv.sum())) == (st.NormalsWrongMagnitude, st.UVInvalid) == (rst["normals_wrong_magnitude"], rst["uv_invalid"])
+    if name == "Zoo":
+        ground = [i for i, o in enumerate(sc.SceneObjects) if o.Name == "ground"][0]
+        assert nw[ground] > 0 and nw[ground] >= 0.9 * nw.sum()                   # its normal is (0, 2, 0): InfinitePlane.cs:20-25 keeps it as given
+    plain = rt.RenderJob(sc, RenderOptions(**kw), device_scene=dev, devices=devices); plain.Wait(); base, _ = plain.ReadAccum()
+    with pytest.raises(Exception):
+        plain.ValidatorCounts()                                                   # a render without the flag keeps no table
+    plain.Dispose()
+    same = (got == base) | (np.isnan(got) & np.isnan(base))
+    assert same.all()
+
+
 @pytest.mark.parametrize("builder", ["device", "ploc", "sah"])
 @pytest.mark.parametrize("name", ["Testing", "MiniMesh", "MiniManyLights", "Zoo", "RgbSpheres"])
 def test_device_built_tree_gives_the_same_hits(pairs, name, builder, monkeypatch):

@@ -153,3 +153,21 @@ def test_oracle_render_is_deterministic_and_partition_independent():
     assert np.allclose(e + f, a, rtol=1e-5, atol=1e-6)
     assert st["pixels_rendered"] == 48 * 27 * 4 and st["ray_count"] > st["pixels_rendered"]
     assert st["sky_rays"] + st["bounce_limit_exceeded"] == st["pixels_rendered"]      # no material absorbs (Scatter never returns null)
+
+
+def test_validator_errors_are_filed_per_object():
+    """GraphicsValidator.Errors[type][object] (GraphicsValidator.cs:18, 35-45; RenderJob.cs:597, 606): the Zoo scene's ground plane was built
+    with the normal (0, 2, 0), which InfinitePlane.cs:20-25 keeps as given, so every hit on it fails CheckVectorNormalized; the only other
+    object that ever does is the cylinder, whose cap normal is the axis divided by its squared length (Cylinder.cs:88)."""
+    import helpers
+    from raytracer_amd.core import RenderOptions
+    from raytracer_amd.flatten import flatten_scene
+    sc = helpers.zoo_scene(); orc = ob.OracleScene(flatten_scene(sc))
+    opt = RenderOptions(RenderWidth=64, RenderHeight=36, Passes=2, MaxBounceDepth=5, Seed=3)
+    _, st, nw, uv = orc.render_validated(opt, threads=4)
+    ground = [i for i, o in enumerate(sc.SceneObjects) if o.Name == "ground"][0]
+    cyl = [i for i, o in enumerate(sc.SceneObjects) if o.Name == "cyl"][0]
+    assert nw[ground] > 0 and set(np.nonzero(nw)[0]) <= {ground, cyl} and nw.sum() == st["normals_wrong_magnitude"]
+    assert uv.sum() == st["uv_invalid"]
+    _, st2 = orc.render(opt, threads=4)
+    assert (st2["normals_wrong_magnitude"], st2["uv_invalid"], st2["ray_count"]) == (st["normals_wrong_magnitude"], st["uv_invalid"], st["ray_count"])
