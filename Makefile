@@ -16,7 +16,7 @@ CALIB := tools/calib_fetch
 
 all: $(LIB) $(ORC) $(BENCH) $(CALIB)
 
-HDRS := $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_wide.h $(CSRC)/rt_bvh.h include/rt_hip.h
+HDRS := $(CSRC)/rt_kernels.h $(CSRC)/rt_device.h $(CSRC)/rt_wide.h $(CSRC)/rt_ldsw.h $(CSRC)/rt_bvh.h include/rt_hip.h
 OBJS := $(addprefix build/,rt_lib.o rt_lbvh.o rt_ploc.o rt_sah.o rt_wide.o rt_bvh.o rt_variant_spheres.o rt_variant_mesh.o rt_variant_boxes.o rt_variant_all.o)
 
 build/%.o: $(CSRC)/%.hip $(HDRS)

@@ -440,12 +440,13 @@ int rt_render_validator_counts(rt_render* render, uint64_t* normals_wrong, uint6
 int rt_trace_closest(rt_scene* scene, const rt_ray* rays, uint64_t n, float k_min, float k_max, uint64_t seed, rt_hit* hits);
 int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* k_min, const float* k_max, uint64_t n, uint8_t* occluded);
 
-/* rt_trace_closest for callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc, code
- * that runs while another thread captures a HIP graph.  It has NO counterpart in the reference.  Same arguments, same kernel and
- * bit-identical results as rt_trace_closest, but the device copies of `rays` and `hits` (rt_trace_closest hipMallocs and frees two
- * buffers per call) are staged in a fixed array inside the library's code object: (sizeof(rt_ray) + sizeof(rt_hit)) *
- * RT_TRACE_NOALLOC_MAX_RAYS = 9.4 MB per GPU, held from library load until the process ends.  The call performs no hipMalloc,
- * hipFree or other allocating routine.  n > RT_TRACE_NOALLOC_MAX_RAYS -> RT_ERR_TOO_LARGE (split the batch, or use rt_trace_closest).
+/* rt_trace_closest for callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc.  It has NO
+ * counterpart in the reference.  Same arguments, same kernel and bit-identical results as rt_trace_closest, but the device copies of
+ * `rays` and `hits` (rt_trace_closest keeps grow-only staging buffers in the scene: its first call, and every larger one, hipMallocs)
+ * are staged in a fixed array inside the library's code object: (sizeof(rt_ray) + sizeof(rt_hit)) * RT_TRACE_NOALLOC_MAX_RAYS = 9.4 MB
+ * per GPU, held from library load until the process ends.  The call performs no hipMalloc, hipFree or other allocating routine; its
+ * two copies and its launch go to a non-blocking stream the library keeps per device (created with the scene), so it does not touch
+ * the null stream.  n > RT_TRACE_NOALLOC_MAX_RAYS -> RT_ERR_TOO_LARGE (split the batch, or use rt_trace_closest).
  * Every call on one GPU shares that GPU's array (it keeps the previous call's contents; entries >= n are stale, never read):
  * calls that overlap on one GPU race — serialise them per device, whatever scenes they use. */
 #define RT_TRACE_NOALLOC_MAX_RAYS (1u << 17)

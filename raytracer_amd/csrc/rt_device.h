@@ -133,6 +133,10 @@ struct SceneDev {
     const uint4* wide_nodes;     uint32_t wide_stride;       // bytes from one node record to the next
     const char* wide_leaves;     uint32_t wide_leaf_stride;  // leaf-ordered records: the object's exact box, its id and code, then (wide_inline) a copy of its primitive
     uint32_t wide_inline;        // the hittable type whose record follows every leaf's box (the tree holds that type only), or RT_NO_HIT
+    // small all-sphere scenes, alternative to lds_image: the W-wide tree with full-precision boxes laid out for LDS (rt_ldsw.h), null otherwise
+    const uint4* ldsw_image;     uint32_t ldsw_node_bytes;   // nodes, then spheres[n_objects], then boxes[n_objects] (2 x float4 each)
+    uint32_t ldsw_any_bytes, ldsw_all_bytes;                 // what an any-hit kernel copies (nodes + spheres) / a closest-hit kernel (+ boxes)
+    uint32_t ldsw_axis_a, ldsw_axis_b;                       // W = 4: the two axes the quadrant slots are laid out along
 };
 
 struct Ray { f3 o, d; };
@@ -799,7 +803,9 @@ struct WideRay {              // what a node visit of the wide tree needs of the
 };
 template <class C> RT_FN void closest_wide(const SceneDev& sc, const WideTree& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt);
 template <class C> RT_FN bool any_wide(const SceneDev& sc, const WideTree& tree, const WideRay& wr, const Ray& r, float kMin, float kMax, TravCount& cnt);
-RT_FN WideRay wide_ray_any(const SceneDev& sc, const Ray& r, float kMax, float cap, int mode, bool& again);
+RT_FN WideRay wide_ray_any(const SceneDev& sc, const WideTree& tree, const Ray& r, float kMax, float cap, int mode, bool& again);
+// (rt_ldsw.h: the W-wide tree in LDS has overloads of the same three names for its own tree and ray types; the calls below depend on
+//  the tree's type, so they are resolved where the kernels are instantiated)
 
 template <class C, class Tree>
 RT_FN Closest closest_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, float kMax, const RngKey& key, uint32_t depth, TravCount& cnt) {
@@ -858,7 +864,7 @@ RT_FN bool any_hit(const SceneDev& sc, const Tree& tree, Ray r, float kMin, floa
     bool again;
     if constexpr (Tree::wide) {
         for (int look = 0;; look = 1) {                          // once, or twice (see any_box)
-            const auto wr = wide_ray_any(sc, r, kMax, cap, look, again);
+            const auto wr = wide_ray_any(sc, tree, r, kMax, cap, look, again);
             if (any_wide<C>(sc, tree, wr, r, kMin, kMax, cnt)) return true;
             if (!again) return false;
         }

@@ -17,6 +17,7 @@
 #pragma once
 #include "rt_device.h"
 #include "rt_wide.h"
+#include "rt_ldsw.h"
 
 namespace rtd {
 
@@ -208,15 +209,32 @@ extern __shared__ int lds_stack[];   // HbmTree: int [stack_depth][block] ; LdsT
 #define RT_LDS_BLOCK_SHADOW 1024
 #endif
 constexpr int LDS_BLOCK_CLOSEST = 1024, LDS_BLOCK_SHADOW = RT_LDS_BLOCK_SHADOW;
+// the closest-hit kernels over the W-wide LDS tree: 79 VGPRs as they come (8 waves per SIMD would spill 28-39 of them), so two workgroups
+// of 768 threads per CU = 6 waves per SIMD
+#ifndef RT_LDSW_CLOSEST_WAVES
+#define RT_LDSW_CLOSEST_WAVES 6
+#endif
+#ifndef RT_LDSW_BLOCK_CLOSEST
+#define RT_LDSW_BLOCK_CLOSEST 768
+#endif
+constexpr int LDSW_BLOCK_CLOSEST = RT_LDSW_BLOCK_CLOSEST;
+constexpr int lds_block_closest(int tree) { return tree == 3 ? LDSW_BLOCK_CLOSEST : LDS_BLOCK_CLOSEST; }
 #ifndef RT_LDS_BLOCK_RAYS
 #define RT_LDS_BLOCK_RAYS 768
 #endif
 constexpr int LDS_BLOCK_RAYS = RT_LDS_BLOCK_RAYS;      // k_shadow_rays with the tree in LDS: 81 VGPRs let 6 waves/SIMD in, two blocks of 12 waves per CU
 // where a traversal kernel reads the tree from: the binary tree through the caches, the binary tree in LDS, the 8-wide tree through the caches
-enum : int { TREE_HBM = 0, TREE_LDS = 1, TREE_WIDE = 2 };
-template <int TREE, int TB>
+enum : int { TREE_HBM = 0, TREE_LDS = 1, TREE_WIDE = 2, TREE_LDSW = 3 };      // LDSW: the W-wide tree in LDS (rt_ldsw.h)
+constexpr bool tree_in_lds(int tree) { return tree == TREE_LDS || tree == TREE_LDSW; }
+template <int TREE, int TB, bool CLOSEST = true>
 RT_FN auto make_tree(const SceneDev& sc) {
-    if constexpr (TREE == TREE_WIDE) {
+    if constexpr (TREE == TREE_LDSW) {
+        uint4* dst = (uint4*)lds_stack;
+        const uint32_t bytes = CLOSEST ? sc.ldsw_all_bytes : sc.ldsw_any_bytes;      // (any-hit has no leaf box test: its kernels leave the boxes out)
+        for (uint32_t i = threadIdx.x; i < bytes / 16; i += TB) dst[i] = sc.ldsw_image[i];
+        __syncthreads();
+        return LdswTree::carve(lds_stack, sc.ldsw_node_bytes, sc.n_objects, bytes, (int)threadIdx.x, TB);
+    } else if constexpr (TREE == TREE_WIDE) {
         WideTree t; t.stack = (uint2*)lds_stack + threadIdx.x; t.stride = TB;
         return t;
     } else if constexpr (TREE == TREE_LDS) {
@@ -236,9 +254,9 @@ RT_FN auto make_tree(const SceneDev& sc) {
 // (primary_ray).  A kernel of its own so that the ray set-up does not cost the bounce launches registers (LDS tree: 57 -> 68 VGPRs
 // would leave room for one 1024-thread workgroup per CU instead of two); held to the same 8 waves per SIMD.
 template <class C, int TREE, bool PRIMARY = false>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK, TREE == TREE_LDS && PRIMARY ? 8 : 1) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
-    constexpr bool LDS = TREE == TREE_LDS;
-    constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+__global__ void __launch_bounds__(tree_in_lds(TREE) ? lds_block_closest(TREE) : BLOCK, TREE == TREE_LDS && PRIMARY ? 8 : TREE == TREE_LDSW ? RT_LDSW_CLOSEST_WAVES : 1) k_closest(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = tree_in_lds(TREE);
+    constexpr int TB = LDS ? lds_block_closest(TREE) : BLOCK;
     const auto tree = make_tree<TREE, TB>(sc);
     constexpr bool primary = PRIMARY;
     const uint32_t n = primary ? rd.n_paths : rd.qcount[depth];
@@ -683,10 +701,10 @@ __global__ void __launch_bounds__(BLOCK, VIS || VALIDATE ? 1 : SHADE_MIN_WAVES) 
 // 4 waves = 128 VGPRs instead of its 157 spills 22 of them and is slower, 56.9 vs 53.5 ms per batch)
 template <class C> struct ShadowTune { static constexpr int min_waves = 1; };
 template <class C, int TREE, bool EXACT = false>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_LDS ? RT_SHADOW_LDS_WAVES : ShadowTune<C>::min_waves) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
-    constexpr bool LDS = TREE == TREE_LDS;
+__global__ void __launch_bounds__(tree_in_lds(TREE) ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : tree_in_lds(TREE) ? RT_SHADOW_LDS_WAVES : ShadowTune<C>::min_waves) k_shadow(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool LDS = tree_in_lds(TREE);
     constexpr int TB = LDS ? LDS_BLOCK_SHADOW : BLOCK;
-    const auto tree = make_tree<TREE, TB>(sc);
+    const auto tree = make_tree<TREE, TB, false>(sc);
     const uint32_t n = rd.sqcount[depth];
     const bool compact = requests_are_compact(rd, depth);
     uint32_t rays = 0;                                // per thread: at most a few thousand requests x rays x nodes
@@ -862,7 +880,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
         bool fetched = false;
         if (!lane_busy()) {
             if (flying && again && !occluded) {                                 // ---- unoccluded in the boxes as they are: look again in the grown ones
-                if constexpr (WIDE) { wr = wide_ray_any(sc, r, kMax, rd.any_cap, 1, again); wc = wide_start(wr); }
+                if constexpr (WIDE) { wr = wide_ray_any(sc, tree, r, kMax, rd.any_cap, 1, again); wc = wide_start(wr); }
                 else { box = any_box(sc, r, kMax, rd.any_cap, 1, again); cur = 0; sp = stk_empty(); }
             } else if (flying) {                                                // ---- account for the finished ray
                 flying = false;
@@ -935,7 +953,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
                 }
                 again = false;
                 if (!occluded && sc.n_nodes) {
-                    if constexpr (WIDE) { wr = wide_ray_any(sc, r, kMax, rd.any_cap, 0, again); wc = wide_start(wr); }
+                    if constexpr (WIDE) { wr = wide_ray_any(sc, tree, r, kMax, rd.any_cap, 0, again); wc = wide_start(wr); }
                     else { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = stk_empty(); }
                 }
             }
@@ -1014,8 +1032,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float* accum, uint32_t 
 
 // Parity hooks: one thread per caller-supplied ray, same device functions as the render kernels.
 template <class C, int TREE>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
-    constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK;
+__global__ void __launch_bounds__(tree_in_lds(TREE) ? lds_block_closest(TREE) : BLOCK) k_trace_closest(SceneDev sc, const rt_ray* rays, uint64_t n, float kMin, float kMax, uint64_t seed, rt_hit* hits) {
+    constexpr int TB = tree_in_lds(TREE) ? lds_block_closest(TREE) : BLOCK;
     const auto tree = make_tree<TREE, TB>(sc);
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
@@ -1037,9 +1055,9 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK) 
 }
 
 template <class C, int TREE>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
-    constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK;
-    const auto tree = make_tree<TREE, TB>(sc);
+__global__ void __launch_bounds__(tree_in_lds(TREE) ? LDS_BLOCK_SHADOW : BLOCK) k_trace_any(SceneDev sc, const rt_ray* rays, const float* kMin, const float* kMax, uint64_t n, uint8_t* occluded) {
+    constexpr int TB = tree_in_lds(TREE) ? LDS_BLOCK_SHADOW : BLOCK;
+    const auto tree = make_tree<TREE, TB, false>(sc);
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         Ray r; r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]); r.d = mk3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]);
         TravCount cnt = trav_count_zero();
@@ -1108,6 +1126,15 @@ struct KernelSet {
         void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
         void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
     } wide;
+    // the W-wide tree in LDS (rt_ldsw.h; null when the variant has no LDS forms)
+    struct Ldsw {
+        void (*closest)(SceneDev, RenderDev, uint32_t);
+        void (*closest_primary)(SceneDev, RenderDev, uint32_t);
+        void (*shadow)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_exact)(SceneDev, RenderDev, uint32_t);
+        void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
+        void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+    } ldsw;
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
@@ -1115,7 +1142,8 @@ template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char
                 nullptr, nullptr, k_shadow_rays<C, false>, k_shadow_rays<C, false, true>, nullptr, nullptr, nullptr, nullptr, k_closest<C, false, true>, nullptr,
                 {k_closest<C, TREE_WIDE>, k_closest<C, TREE_WIDE, true>, k_closest_persistent<C, TREE_WIDE>, k_shadow<C, TREE_WIDE>, k_shadow<C, TREE_WIDE, true>, k_shadow_rays<C, TREE_WIDE>, k_shadow_rays<C, TREE_WIDE, true>,
                  k_shadow_persistent<C, TREE_WIDE>, k_shadow_persistent<C, TREE_WIDE, true>, k_trace_closest<C, TREE_WIDE>, k_trace_any<C, TREE_WIDE>}};
-    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.closest_primary_lds = k_closest<C, true, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>; }
+    if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.closest_primary_lds = k_closest<C, true, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>;
+                               k.ldsw = {k_closest<C, TREE_LDSW>, k_closest<C, TREE_LDSW, true>, k_shadow<C, TREE_LDSW>, k_shadow<C, TREE_LDSW, true>, k_trace_closest<C, TREE_LDSW>, k_trace_any<C, TREE_LDSW>}; }
     return k;
 }
 

@@ -1,0 +1,222 @@
+// rt_ldsw.h — a W-wide tree (W = 4 or 8) with full-precision inner boxes, held in LDS (small all-sphere scenes: Night Spheres).
+//
+// Why: with the tree in LDS nothing waits for memory; the binary traversal (LdsTree, rt_device.h) spends its vector instructions on the
+// bookkeeping around a node — address, child select, push / pop, leaf parking: about 45 of the 70 issue slots of a two-box visit.
+// Only a LEAF's box has reference arithmetic to reproduce (Core/Acceleration/SingleObjectBvhNode.cs:10-16); inner boxes only have to
+// be conservative (BinaryBvhNode.cs:13-37 returns what its children return) and any-hit has no box test at all in the reference
+// (BinaryBvhNode.cs:41).  So W children are tested per visit with ONE fused multiply-add per plane, t = plane * (1/d) + (-(o -+ pad)/d)
+// (the any-hit form of AnyBox, here for closest hit too), and the bookkeeping is paid once per W boxes: the group cursor of rt_wide.h
+// (a node's hit children are one stack entry, not up to W).  A leaf's own box is tested when the leaf is taken, in the reference's
+// arithmetic (slab()), in front of its sphere.
+//
+// LDS image (rt_lib.hip: build_ldsw writes it; every workgroup copies it):
+//   nodes[n]      LDSW_NODE_BYTES each:
+//                   +0   u32  child_base (the first inner child's offset in 16-B units) | imask << 16 | lmask << 24      which slots hold an inner node / a leaf
+//                   +16  u16 x W  object id of the leaf in each slot
+//                   +32  per axis (x, y, z) 3 W floats: min[W] max[W] min[W] — the repeated min block turns the ray's sign into a byte
+//                        offset: read at +0 (near, far) = (min, max) for a ray along +axis, at +4W bytes (max, min) along -axis
+//                 the k-th inner child (slots ascending) is the record at child_base + k * LDSW_NODE_UNITS
+//   spheres[n_objects]   float4 by object id
+//   boxes[n_objects]     6 floats by object id (min.xyz, max.xyz): the object's exact box (closest-hit kernels only: the any-hit kernels copy the image up to here)
+// Slots are assigned by quadrant / octant (Ylitie, Karras, Laine 2017; W = 4: by the two axes along which the scene is largest), so
+// visiting the hit slots by descending (slot XOR octinv) is front to back with no sorting.
+#pragma once
+#include "rt_wide.h"
+
+namespace rtd {
+
+#ifndef RT_LDSW
+#define RT_LDSW 4
+#endif
+#ifndef RT_LDSW_DEFAULT
+#define RT_LDSW_DEFAULT 1          // 1: the any-hit kernels of scenes whose tree fits LDS in both forms walk the W-wide one unless RT_HIP_LDS_WIDE=0 (=2: the closest-hit kernels too)
+#endif
+constexpr int LDSW = RT_LDSW;
+static_assert(LDSW == 4 || LDSW == 8, "slots per node of the LDS wide tree");
+constexpr uint32_t LDSW_AXIS_BYTES = 12u * LDSW, LDSW_HEAD_BYTES = 32u, LDSW_NODE_BYTES = LDSW_HEAD_BYTES + 3u * LDSW_AXIS_BYTES, LDSW_NODE_UNITS = LDSW_NODE_BYTES / 16u;
+constexpr uint32_t LDSW_BOX_BYTES = 24u;
+// a stack entry = a group: first node | (hits | imask << 8) << 16
+constexpr uint32_t LDSW_MAX_NODES = 65536u / LDSW_NODE_UNITS;      // (a node is named by its offset in 16-B units, in 16 bits)
+typedef uint32_t LdswEntry;
+RT_FN LdswEntry ldsw_pack(uint32_t gbase, uint32_t gbits) { return gbase | (gbits << 16); }
+RT_FN void ldsw_unpack(uint32_t e, uint32_t& gbase, uint32_t& gbits) { gbase = e & 0xFFFFu; gbits = e >> 16; }
+
+struct LdswTree {
+    static constexpr bool wide = true;
+    static constexpr bool list = false;
+    const char* nodes; const float4* sph; const float2* boxes;
+    LdswEntry* stack; int stride;                // this lane's column of group entries (ldsw_pack)
+    RT_FN void push(int sp, LdswEntry v) const { stack[sp * stride] = v; }
+    RT_FN uint32_t pop(int sp) const { return stack[sp * stride]; }
+    RT_FN static LdswTree carve(const void* base, uint32_t node_bytes, uint32_t n_objects, uint32_t copied_bytes, int tid, int block) {
+        LdswTree t;
+        t.nodes = (const char*)base;
+        t.sph = (const float4*)((const char*)base + node_bytes);
+        t.boxes = (const float2*)(t.sph + n_objects);
+        t.stack = (LdswEntry*)((const char*)base + copied_bytes) + tid; t.stride = block;
+        return t;
+    }
+};
+
+// what a node visit needs of the ray: per axis 1/d (clamped), the two addends of the near and the far plane, the byte offset of the near block
+// ORDERED: the hit slots of a node are entered front to back (closest hit).  Any-hit rays enter them in slot order: in a tree this small
+// the order saves less than the two mask permutations per visit cost (as for the binary LDS tree, whose any-hit walk is unordered too).
+struct LdswRay { f3 inv, an, af; uint32_t ox, oy, oz, octinv; };
+template <bool ORDERED>
+RT_FN LdswRay make_ldsw_ray(const SceneDev& sc, const Ray& r, f3 inv, float pad, float lim) {
+    LdswRay q;
+    const float dd[3] = {r.d.x, r.d.y, r.d.z}, oo[3] = {r.o.x, r.o.y, r.o.z}, ii[3] = {inv.x, inv.y, inv.z};
+    float in_[3], an_[3], af_[3]; uint32_t off[3], neg = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const bool ng = __builtin_signbitf(dd[i]);
+        const float sp = ng ? -pad : pad;
+        in_[i] = __builtin_fminf(__builtin_fmaxf(ii[i], -lim), lim);
+        an_[i] = -(oo[i] + sp) * in_[i];             // near plane: the min plane moved by -pad for a ray along +axis, the max plane moved by +pad otherwise
+        af_[i] = -(oo[i] - sp) * in_[i];
+        off[i] = ng ? 4u * LDSW : 0u;
+        neg |= ng ? 1u << i : 0u;
+    }
+    q.inv = mk3(in_[0], in_[1], in_[2]); q.an = mk3(an_[0], an_[1], an_[2]); q.af = mk3(af_[0], af_[1], af_[2]);
+    q.ox = off[0]; q.oy = off[1]; q.oz = off[2];
+    if (!ORDERED) q.octinv = 0u;
+    else if (LDSW == 8) q.octinv = 7u ^ neg;
+    else q.octinv = 3u ^ (((neg >> sc.ldsw_axis_a) & 1u) | (((neg >> sc.ldsw_axis_b) & 1u) << 1));
+    return q;
+}
+// Closest hit: planes moved outward by 1e-6 of the farthest the scene reaches from the ray origin (see wide_ray_closest: the FMA form and
+// the reference's fl(fl(plane - o) * inv) of the leaf test differ by at most 3.6e-7 of that), so a visit never culls a leaf whose own test would pass.
+RT_FN LdswRay ldsw_ray_closest(const SceneDev& sc, const Ray& r, f3 inv_exact) {
+    const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
+    const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;
+    return make_ldsw_ray<true>(sc, r, inv_exact, (1e-6f * far_side) + 1e-30f, WIDE_INV_LIMIT * __builtin_amdgcn_rsqf(dot(r.d, r.d)));
+}
+// Any hit: the pad of any_box (rt_device.h) — two looks, first with none.
+RT_FN LdswRay wide_ray_any(const SceneDev& sc, const LdswTree&, const Ray& r, float kMax, float cap, int mode, bool& again) {
+    const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
+    const float len = __builtin_amdgcn_sqrtf(dot(r.d, r.d));
+    const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;
+    const float range = kMax * len;
+    const float reach = (range < far_side ? range : far_side) + sc.max_object_radius;
+    float round = 0.0f, rm = 3e38f;
+    if (sc.min_round_radius < 3e38f) {
+        rm = sc.min_round_radius;
+        round = __builtin_fminf((__builtin_amdgcn_sqrtf((rm * rm) + (1.1e-6f * reach * reach)) - rm) * 1.02f, cap * rm);
+    }
+    again = mode == 0 && round > (sc.any_again * rm);
+    const f3 inv = mk3(rcp_fast(r.d.x), rcp_fast(r.d.y), rcp_fast(r.d.z));
+    const float lim = WIDE_INV_LIMIT * rcp_fast(len);
+    if (again) return make_ldsw_ray<false>(sc, r, inv, 0.0f, lim);
+    return make_ldsw_ray<false>(sc, r, inv, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))), lim);
+}
+
+RT_FN uint32_t xor_permute_w(uint32_t m, uint32_t x) {      // position p of a W-bit mask -> position p ^ x
+    if (LDSW == 8 && (x & 4u)) m = ((m & 0x0Fu) << 4) | ((m >> 4) & 0x0Fu);
+    if (x & 2u) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (x & 1u) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    return m;
+}
+
+// One node: which of its W child boxes the ray's [kMin, kMax] meets (slot order).  `head` returns the node's first word.
+RT_FN uint32_t ldsw_visit(const LdswTree& t, const LdswRay& q, uint32_t node, float kMin, float kMax, uint32_t& head) {
+    const char* n = t.nodes + (node << 4);
+    head = *(const uint32_t*)n;
+    const char* ax = n + LDSW_HEAD_BYTES + q.ox;
+    const char* ay = n + LDSW_HEAD_BYTES + LDSW_AXIS_BYTES + q.oy;
+    const char* az = n + LDSW_HEAD_BYTES + 2u * LDSW_AXIS_BYTES + q.oz;
+    const v2f ix = {q.inv.x, q.inv.x}, iy = {q.inv.y, q.inv.y}, iz = {q.inv.z, q.inv.z};
+    const v2f anx = {q.an.x, q.an.x}, any_ = {q.an.y, q.an.y}, anz = {q.an.z, q.an.z};
+    const v2f afx = {q.af.x, q.af.x}, afy = {q.af.y, q.af.y}, afz = {q.af.z, q.af.z};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int g = 0; g < LDSW / 4; g++) {
+        const float4 nx = *(const float4*)(ax + 16 * g), fx = *(const float4*)(ax + 4 * LDSW + 16 * g);
+        const float4 ny = *(const float4*)(ay + 16 * g), fy = *(const float4*)(ay + 4 * LDSW + 16 * g);
+        const float4 nz = *(const float4*)(az + 16 * g), fz = *(const float4*)(az + 4 * LDSW + 16 * g);
+        const v2f nx0 = __builtin_elementwise_fma((v2f){nx.x, nx.y}, ix, anx), nx1 = __builtin_elementwise_fma((v2f){nx.z, nx.w}, ix, anx);
+        const v2f ny0 = __builtin_elementwise_fma((v2f){ny.x, ny.y}, iy, any_), ny1 = __builtin_elementwise_fma((v2f){ny.z, ny.w}, iy, any_);
+        const v2f nz0 = __builtin_elementwise_fma((v2f){nz.x, nz.y}, iz, anz), nz1 = __builtin_elementwise_fma((v2f){nz.z, nz.w}, iz, anz);
+        const v2f fx0 = __builtin_elementwise_fma((v2f){fx.x, fx.y}, ix, afx), fx1 = __builtin_elementwise_fma((v2f){fx.z, fx.w}, ix, afx);
+        const v2f fy0 = __builtin_elementwise_fma((v2f){fy.x, fy.y}, iy, afy), fy1 = __builtin_elementwise_fma((v2f){fy.z, fy.w}, iy, afy);
+        const v2f fz0 = __builtin_elementwise_fma((v2f){fz.x, fz.y}, iz, afz), fz1 = __builtin_elementwise_fma((v2f){fz.z, fz.w}, iz, afz);
+        const float tn[4][3] = {{nx0.x, ny0.x, nz0.x}, {nx0.y, ny0.y, nz0.y}, {nx1.x, ny1.x, nz1.x}, {nx1.y, ny1.y, nz1.y}};
+        const float tf[4][3] = {{fx0.x, fy0.x, fz0.x}, {fx0.y, fy0.y, fz0.y}, {fx1.x, fy1.x, fz1.x}, {fx1.y, fy1.y, fz1.y}};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // (a NaN distance — inf - inf on an axis the ray is parallel to — never replaces a bound: maxNum / minNum)
+            const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tn[j][0], tn[j][1]), tn[j][2]), kMin);
+            const float ex = __builtin_fminf(__builtin_fminf(__builtin_fminf(tf[j][0], tf[j][1]), tf[j][2]), kMax);
+            hits |= !(ex < en) ? (1u << (4 * g + j)) : 0u;                                   // closed interval: a box met on a face or an edge is entered
+        }
+    }
+    return hits;
+}
+
+// the traversal state is rt_wide.h's WideCursor; gbase = the group's first node, pbase = the node whose leaves are in P
+RT_FN WideCursor ldsw_start(const LdswRay& q) { WideCursor c = wide_idle(); c.gbits = (1u << q.octinv) | (1u << 8); return c; }      // the root as a one-child group: node 0 in slot 0
+
+// Enter the next child still in G (ORDERED: the nearest) and test its children.  Returns the number of boxes tested.
+template <bool ORDERED>
+RT_FN uint32_t ldsw_step(const LdswTree& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) {
+    const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.gbits & 0xFFu);
+    const uint32_t slot = ORDERED ? pi ^ q.octinv : pi, gmask = (c.gbits >> 8) & 0xFFu;
+    const uint32_t node = c.gbase + __umul24((uint32_t)__builtin_popcount(gmask & ((1u << slot) - 1u)), LDSW_NODE_UNITS);
+    const uint32_t rest = c.gbits & ~(1u << pi);                 // the siblings still to enter
+    uint32_t head;
+    const uint32_t hits = ldsw_visit(tree, q, node, kMin, kMax, head);
+    const uint32_t imask = (head >> 16) & 0xFFu, lmask = head >> 24;
+    c.pbase = node; c.pbits = (ORDERED ? xor_permute_w(hits & lmask, q.octinv) : hits & lmask) | (lmask << 8);
+    const uint32_t inner = hits & imask;
+    if (inner) {                                                  // descend: the siblings wait in the lane's column
+        if (rest & 0xFFu) { tree.push(c.sp, ldsw_pack(c.gbase, rest)); c.sp++; }
+        c.gbase = head & 0xFFFFu; c.gbits = (ORDERED ? xor_permute_w(inner, q.octinv) : inner) | (imask << 8);
+    } else if (rest & 0xFFu) c.gbits = rest;                      // nothing below: on with the siblings
+    else if (c.sp) { c.sp--; ldsw_unpack(tree.pop(c.sp), c.gbase, c.gbits); }
+    else c.gbits = 0;
+    return (uint32_t)__builtin_popcount(imask | lmask);
+}
+// the next leaf of P: its object id
+template <bool ORDERED>
+RT_FN uint32_t ldsw_take_leaf(const LdswTree& tree, WideCursor& c, const LdswRay& q) {
+    const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.pbits & 0xFFu);
+    const uint32_t slot = ORDERED ? pi ^ q.octinv : pi;
+    c.pbits &= ~(1u << pi);
+    return *(const unsigned short*)(tree.nodes + (c.pbase << 4) + 16u + 2u * slot);
+}
+
+// the tree part of closest_hit (rt_device.h).  Lanes step until they hold a leaf (rays of about equal cost: no votes, as for LdsTree).
+template <class C>
+RT_FN void closest_wide(const SceneDev& sc, const LdswTree& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt) {
+    const f3 inv = splat(1.0f) / r.d;
+    const LdswRay q = ldsw_ray_closest(sc, r, inv);
+    WideCursor c = ldsw_start(q);
+    for (;;) {
+        while (wide_can_step(c)) cnt.nodes += ldsw_step<true>(tree, q, kMin, best.k, c);
+        if (wide_has_leaf(c)) {
+            // the object's own box first, in the reference's arithmetic (AxisAlignedBoundingBox.Hit through slab(): SingleObjectBvhNode.cs:12-16), then Hittable.TryHit
+            const uint32_t obj = ldsw_take_leaf<true>(tree, c, q);
+            const float2 b0 = tree.boxes[3 * obj], b1 = tree.boxes[3 * obj + 1], b2 = tree.boxes[3 * obj + 2];
+            float entry, exit_;
+            cnt.nodes++;
+            slab(mk3(b0.x, b0.y, b1.x), mk3(b1.y, b2.x, b2.y), r.o, inv, kMin, entry, exit_);
+            if (!slab_hit(entry, exit_, best.k)) cnt.box_miss++;
+            else {
+                float k; cnt.prims++;
+                if (try_sphere(tree.sph[obj], r, kMin, best.k, k)) { consider(best, k, obj, 0.0f); cnt.prim_hit++; }
+            }
+        }
+        if (!wide_busy(c)) break;
+    }
+}
+// the tree part of any_hit: one look with the pad of `q`.  Hittable.FastTryHit, no box test at the leaf (BinaryBvhNode.cs:41).
+template <class C>
+RT_FN bool any_wide(const SceneDev& sc, const LdswTree& tree, const LdswRay& q, const Ray& r, float kMin, float kMax, TravCount& cnt) {
+    WideCursor c = ldsw_start(q);
+    for (;;) {
+        while (wide_can_step(c)) cnt.nodes += ldsw_step<false>(tree, q, kMin, kMax, c);
+        if (wide_has_leaf(c)) { float k; cnt.prims++; if (try_sphere(tree.sph[ldsw_take_leaf<false>(tree, c, q)], r, kMin, kMax, k)) return true; }
+        if (!wide_busy(c)) return false;
+    }
+}
+
+} // namespace rtd

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <array>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <atomic>
@@ -81,7 +83,7 @@ constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 
 // every device buffer of a scene (X-macro: allocation, peer copy to a replica, pointer binding all walk the same list)
 #define RT_SCENE_BUFFERS(X) \
-    X(nodes) X(wide_nodes) X(wide_leaves) X(list_nodes) X(lds_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
+    X(nodes) X(wide_nodes) X(wide_leaves) X(list_nodes) X(lds_image) X(ldsw_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
     X(axis0) X(axis1) X(axis2) X(disks) X(boxes) X(capsules) X(cylinders) X(media_rec) X(materials) X(textures) X(lights)
 
 struct rt_scene {
@@ -91,6 +93,9 @@ struct rt_scene {
     uint32_t stack_depth = 1;        // per-lane traversal stack entries
     uint32_t bvh_depth = 0;
     bool use_lds = false;            // LdsTree kernels (small all-sphere scene)
+    bool use_ldsw = false;           // ... its any-hit kernels through the W-wide tree in LDS (rt_ldsw.h) instead of the binary one (use_lds stays set: everything else about "tree in LDS" holds)
+    bool use_ldsw_closest = false;   // ... and its closest-hit kernels too (RT_HIP_LDS_WIDE=2)
+    uint32_t ldsw_count = 0, ldsw_levels = 0;
     bool use_wide = false;           // WideTree kernels (rt_wide.h): the 8-wide tree made from the binary one, for trees read through the caches
     uint32_t wide_count = 0, wide_levels = 0;
     bool device_build = false;       // the tree was built by rt_lbvh.hip
@@ -113,7 +118,7 @@ namespace {
 // SceneDev's pointers from the scene's own buffers (after upload, and after a replica's peer copies)
 void bind_scene_pointers(rt_scene* s) {
     SceneDev& sd = s->dev;
-    sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>();
+    sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>(); sd.ldsw_image = s->ldsw_image.as<uint4>();
     sd.wide_nodes = s->wide_nodes.as<uint4>(); sd.wide_leaves = s->wide_leaves.as<char>();
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>();
     sd.obj_shade = s->obj_shade.bytes ? s->obj_shade.as<float4>() : nullptr;
@@ -131,6 +136,8 @@ int allow_big_lds(const KernelSet* ks) {
     const void* fns[8] = {(const void*)ks->closest_primary_lds, (const void*)ks->closest_lds, (const void*)ks->trace_closest_lds, (const void*)ks->shadow_lds, (const void*)ks->trace_any_lds, (const void*)ks->shadow_lds_exact,
                           (const void*)ks->shadow_rays_lds, (const void*)ks->shadow_rays_lds_exact};
     for (const void* f : fns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
+    const void* wfns[6] = {(const void*)ks->ldsw.closest, (const void*)ks->ldsw.closest_primary, (const void*)ks->ldsw.shadow, (const void*)ks->ldsw.shadow_exact, (const void*)ks->ldsw.trace_closest, (const void*)ks->ldsw.trace_any};
+    for (const void* f : wfns) if (f) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_CAP));
     return RT_OK;
 }
 } // namespace
@@ -218,17 +225,173 @@ static __device__ __align__(256) unsigned char scratch[RT_TRACE_NOALLOC_MAX_RAYS
 namespace {
 constexpr int MAX_DEVICES = 64;
 void* g_scratch[MAX_DEVICES] = {};
+hipStream_t g_scratch_stream[MAX_DEVICES] = {};      // one non-blocking stream per device for rt_trace_closest_noalloc: nothing of it touches the null stream
 std::mutex g_scratch_mutex;
 // the current device must be `device`
 int scratch_for_device(int device) {
     if (device < 0 || device >= MAX_DEVICES) return fail(RT_ERR_INVALID_ARG, "device %d beyond the %d this library keeps scratch for", device, MAX_DEVICES);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (g_scratch[device]) return RT_OK;
+    if (g_scratch[device] && g_scratch_stream[device]) return RT_OK;
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    if (!g_scratch_stream[device]) HIP_TRY(hipStreamCreateWithFlags(&g_scratch_stream[device], hipStreamNonBlocking));      // (a stream is no device allocation; kept until the process ends)
     g_scratch[device] = p;
     return RT_OK;
+}
+} // namespace
+
+
+namespace {
+// The W-wide tree for LDS (rt_ldsw.h) from the host's binary tree: a node takes over its larger inner children's children until it has
+// W of them (largest surface area first), its children sit in the slots of their quadrant / octant, and the inner children of one node
+// get consecutive indices (breadth first).  Returns false when the tree does not fit the format (more nodes than a stack entry can name).
+struct LdswBuild { std::vector<unsigned char> nodes; uint32_t n_nodes = 0, levels = 0, axis_a = 0, axis_b = 2; };
+bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
+    constexpr int W = LDSW;
+    struct Kid { float mn[3], mx[3]; int code; };
+    auto kid = [&](int node, int side) { Kid k; const rtbvh::HostNode& h = bin[node]; for (int a = 0; a < 3; a++) { k.mn[a] = h.q[2 * a + side]; k.mx[a] = h.q[6 + 2 * a + side]; } k.code = side ? h.childB : h.childA; return k; };
+    auto area = [](const Kid& k) { const double x = (double)k.mx[0] - k.mn[0], y = (double)k.mx[1] - k.mn[1], z = (double)k.mx[2] - k.mn[2]; return x * y + y * z + z * x; };
+    {   // W = 4: the quadrants follow the two axes along which the whole tree is largest
+        const Kid a = kid(0, 0), b = kid(0, 1);
+        double ext[3]; for (int i = 0; i < 3; i++) ext[i] = (double)std::max(a.mx[i], b.mx[i]) - std::min(a.mn[i], b.mn[i]);
+        int smallest = 0; for (int i = 1; i < 3; i++) if (ext[i] < ext[smallest]) smallest = i;
+        out.axis_a = smallest == 0 ? 1 : 0; out.axis_b = smallest == 2 ? 1 : 2;
+    }
+    // Which W subtrees a node takes as its children: the choice that minimises the expected number of node visits, sum over the wide nodes
+    // of their surface area (Ylitie, Karras, Laine 2017, section 3.1: cost[n][j] = the best cost of the binary subtree n as a forest of at most
+    // j + 1 wide subtrees; a leaf costs the same wherever it hangs, so it counts 0).  Greedy "open the largest child" left 263 nodes of
+    // 2.8 children for Night Spheres' 484 leaves.
+    const size_t nb = bin.size();
+    std::vector<double> node_area(nb, 0.0);
+    std::vector<std::array<double, W>> cost(nb);
+    auto sub_area = [&](int code, const Kid& as_child) { return code >= 0 ? node_area[code] : area(as_child); };
+    (void)sub_area;
+    std::vector<int> order; order.reserve(nb);      // parents before children; walked backwards for the bottom-up pass
+    { std::vector<int> st{0}; while (!st.empty()) { const int n = st.back(); st.pop_back(); order.push_back(n); for (int side = 0; side < 2; side++) { const int c = side ? bin[n].childB : bin[n].childA; if (c >= 0) st.push_back(c); } } }
+    auto cost_of = [&](int code, int j) { return code >= 0 ? cost[code][j] : 0.0; };      // j = roots allowed - 1
+    for (size_t oi = order.size(); oi-- > 0;) {
+        const int n = order[oi];
+        const Kid a = kid(n, 0), b = kid(n, 1);
+        Kid u = a; if (b.code != rtbvh::CHILD_EMPTY) for (int x = 0; x < 3; x++) { u.mn[x] = std::min(u.mn[x], b.mn[x]); u.mx[x] = std::max(u.mx[x], b.mx[x]); }
+        node_area[n] = area(u);
+        const int ca = a.code, cb = b.code == rtbvh::CHILD_EMPTY ? -1 : b.code;
+        auto distribute = [&](int roots) {      // the subtree as `roots` (>= 2) subtrees: k of them from the left child, the others from the right
+            double best = INFINITY;
+            for (int k = 1; k < roots; k++) best = std::min(best, cost_of(ca, k - 1) + cost_of(cb, roots - k - 1));
+            return best;
+        };
+        cost[n][0] = node_area[n] + distribute(W);                                     // one wide node here, its W children below
+        for (int j = 1; j < W; j++) cost[n][j] = std::min(distribute(j + 1), cost[n][j - 1]);
+    }
+    std::function<void(int, const Kid&, int, std::vector<Kid>&)> collect = [&](int code, const Kid& self, int roots, std::vector<Kid>& outk) {
+        if (code < 0 || roots == 1) { outk.push_back(self); return; }
+        if (roots > 1 && cost[code][roots - 1] == cost[code][roots - 2] && roots > 2) { collect(code, self, roots - 1, outk); return; }
+        if (roots == 2 && cost[code][1] == cost[code][0]) { outk.push_back(self); return; }
+        const Kid a = kid(code, 0), b = kid(code, 1);
+        if (b.code == rtbvh::CHILD_EMPTY) { collect(a.code, a, roots, outk); return; }
+        int best_k = 1; double best = INFINITY;
+        for (int k = 1; k < roots; k++) { const double c = cost_of(a.code, k - 1) + cost_of(b.code, roots - k - 1); if (c < best) { best = c; best_k = k; } }
+        collect(a.code, a, best_k, outk); collect(b.code, b, roots - best_k, outk);
+    };
+    struct Todo { int bin_node; uint32_t level; };
+    std::vector<Todo> todo{{0, 1}};           // todo[i] becomes wide node i
+    for (size_t i = 0; i < todo.size(); i++) {
+        if (todo.size() > LDSW_MAX_NODES) return false;
+        std::vector<Kid> kids;
+        {   // the node's own two children, each opened as far as the cost table says: W subtrees in all
+            const Kid a = kid(todo[i].bin_node, 0), b = kid(todo[i].bin_node, 1);
+            if (b.code == rtbvh::CHILD_EMPTY) kids.push_back(a);
+            else {
+                int best_k = 1; double best = INFINITY;
+                for (int k = 1; k < W; k++) { const double c = cost_of(a.code, k - 1) + cost_of(b.code, W - k - 1); if (c < best) { best = c; best_k = k; } }
+                collect(a.code, a, best_k, kids); collect(b.code, b, W - best_k, kids);
+            }
+        }
+        // slots: kid k in slot s scores sum over the slot's axes of (+-)(its centre - the node's centre); greedily the best (kid, slot) pair first
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (const Kid& k : kids) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)k.mn[a]); hi[a] = std::max(hi[a], (double)k.mx[a]); }
+        const int axes[3] = {W == 8 ? 0 : (int)out.axis_a, W == 8 ? 1 : (int)out.axis_b, 2};
+        const int n_axes = W == 8 ? 3 : 2;
+        int slot_of[W]; bool kid_done[W] = {}, slot_used[W] = {};
+        for (size_t placed = 0; placed < kids.size(); placed++) {
+            double best = -INFINITY; int bk = -1, bs = -1;
+            for (int k = 0; k < (int)kids.size(); k++) if (!kid_done[k])
+                for (int sl = 0; sl < W; sl++) if (!slot_used[sl]) {
+                    double sc = 0;
+                    for (int b = 0; b < n_axes; b++) { const int a = axes[b]; const double c = 0.5 * ((double)kids[k].mn[a] + kids[k].mx[a]) - 0.5 * (lo[a] + hi[a]); sc += ((sl >> b) & 1) ? c : -c; }
+                    if (sc > best) { best = sc; bk = k; bs = sl; }
+                }
+            kid_done[bk] = true; slot_used[bs] = true; slot_of[bk] = bs;
+        }
+        // the record
+        out.nodes.resize((i + 1) * LDSW_NODE_BYTES, 0);
+        unsigned char* rec = out.nodes.data() + i * LDSW_NODE_BYTES;
+        float* planes = (float*)(rec + LDSW_HEAD_BYTES);
+        for (int a = 0; a < 3; a++) for (int sl = 0; sl < W; sl++) { planes[3 * W * a + sl] = 3e38f; planes[3 * W * a + W + sl] = -3e38f; planes[3 * W * a + 2 * W + sl] = 3e38f; }      // an empty slot: no ray meets it
+        uint32_t imask = 0, lmask = 0; unsigned short ids[W] = {};
+        int by_slot[W]; for (int sl = 0; sl < W; sl++) by_slot[sl] = -1;
+        for (int k = 0; k < (int)kids.size(); k++) by_slot[slot_of[k]] = k;
+        const uint32_t child_base = (uint32_t)todo.size() * LDSW_NODE_UNITS;      // (16-B units)
+        for (int sl = 0; sl < W; sl++) {
+            if (by_slot[sl] < 0) continue;
+            const Kid& k = kids[by_slot[sl]];
+            for (int a = 0; a < 3; a++) { planes[3 * W * a + sl] = k.mn[a]; planes[3 * W * a + W + sl] = k.mx[a]; planes[3 * W * a + 2 * W + sl] = k.mn[a]; }
+            if (k.code >= 0) { imask |= 1u << sl; todo.push_back({k.code, todo[i].level + 1}); }          // (slots ascending: the k-th inner child is node child_base + k)
+            else { lmask |= 1u << sl; const uint32_t obj = (uint32_t)~k.code; if (obj > 0xFFFFu) return false; ids[sl] = (unsigned short)obj; }
+        }
+        if (child_base + W * LDSW_NODE_UNITS > 65536u) return false;
+        const uint32_t head = child_base | (imask << 16) | (lmask << 24);
+        memcpy(rec, &head, 4); memcpy(rec + 16, ids, sizeof(ids));
+        out.levels = std::max(out.levels, todo[i].level);
+    }
+    if (todo.size() > LDSW_MAX_NODES) return false;
+    out.n_nodes = (uint32_t)todo.size();
+    {   // every leaf of the binary tree hangs in exactly one slot, every node but the root is exactly one node's child, and every child's
+        // box lies inside what the node's slot says: a tree that fails this is not used
+        std::vector<int> seen;
+        size_t bin_leaves = 0, wide_leaves = 0, inner_kids = 0; bool ok = true;
+        auto note = [&](int code) { if (code < 0 && code != rtbvh::CHILD_EMPTY) { bin_leaves++; const size_t o = (size_t)~code; if (seen.size() <= o) seen.resize(o + 1, 0); } };
+        for (const rtbvh::HostNode& h : bin) { note(h.childA); note(h.childB); }
+        std::vector<int> parents(out.n_nodes, 0);
+        for (uint32_t i = 0; i < out.n_nodes; i++) {
+            const unsigned char* rec = out.nodes.data() + (size_t)i * LDSW_NODE_BYTES;
+            uint32_t head; memcpy(&head, rec, 4);
+            const uint32_t imask = (head >> 16) & 0xFFu, lmask = head >> 24;
+            ok = ok && !(imask & lmask);
+            uint32_t rank = 0;
+            for (int sl = 0; sl < W; sl++) {
+                if ((lmask >> sl) & 1u) { unsigned short id; memcpy(&id, rec + 16 + 2 * sl, 2); if (id < seen.size()) seen[id]++; else ok = false; wide_leaves++; }
+                if ((imask >> sl) & 1u) { const uint32_t child = ((head & 0xFFFFu) / LDSW_NODE_UNITS) + rank++; if (child < out.n_nodes) parents[child]++; else ok = false; inner_kids++; }
+            }
+        }
+        // an inner child's record must be the subtree its slot's box was made for: the union of the child's own slots is that box
+        for (uint32_t i = 0; i < out.n_nodes; i++) {
+            const unsigned char* rec = out.nodes.data() + (size_t)i * LDSW_NODE_BYTES;
+            uint32_t head; memcpy(&head, rec, 4);
+            const float* pl = (const float*)(rec + LDSW_HEAD_BYTES);
+            uint32_t rank = 0;
+            for (int sl = 0; sl < W; sl++) if ((head >> (16 + sl)) & 1u) {
+                const uint32_t child = ((head & 0xFFFFu) / LDSW_NODE_UNITS) + rank++;
+                if (child >= out.n_nodes) { ok = false; continue; }
+                const unsigned char* crec = out.nodes.data() + (size_t)child * LDSW_NODE_BYTES;
+                uint32_t chead; memcpy(&chead, crec, 4);
+                const float* cpl = (const float*)(crec + LDSW_HEAD_BYTES);
+                const uint32_t used = ((chead >> 16) | (chead >> 24)) & 0xFFu;
+                for (int a = 0; a < 3; a++) {
+                    float lo = INFINITY, hi = -INFINITY;
+                    for (int cs = 0; cs < W; cs++) if ((used >> cs) & 1u) { lo = std::min(lo, cpl[3 * W * a + cs]); hi = std::max(hi, cpl[3 * W * a + W + cs]); }
+                    ok = ok && lo == pl[3 * W * a + sl] && hi == pl[3 * W * a + W + sl] && pl[3 * W * a + 2 * W + sl] == pl[3 * W * a + sl];
+                }
+            }
+        }
+        for (int c : seen) ok = ok && c <= 1;
+        size_t seen_once = 0; for (int c : seen) seen_once += c == 1;
+        for (uint32_t i = 1; i < out.n_nodes; i++) ok = ok && parents[i] == 1;
+        if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: %d-wide LDS tree: %zu leaves of %zu (%zu distinct), %zu inner children for %u nodes, %s\n", W, wide_leaves, bin_leaves, seen_once, inner_kids, out.n_nodes, ok ? "consistent" : "INCONSISTENT");
+        if (!ok || seen_once != bin_leaves || wide_leaves != bin_leaves || inner_kids + 1 != out.n_nodes) return false;
+    }
+    return true;
 }
 } // namespace
 
@@ -585,6 +748,31 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             sd.lds_image = s->lds_image.as<uint4>(); sd.lds_image_bytes = (uint32_t)image_bytes;
             s->use_lds = true;
             if ((rc = allow_big_lds(ks))) return rc;
+            // ... and the same tree W-wide (rt_ldsw.h): the kernels that walk it are the default when both forms fit (RT_HIP_LDS_WIDE=0: the
+            // binary form).  The kernels it has no form of (ray lanes, persistent lanes: both measured slower with the tree in LDS) keep
+            // the binary image, so forcing one of those leaves this out.
+            const char* ew = getenv("RT_HIP_LDS_WIDE");
+            const bool want_w = ew ? (ew[0] == '1' || ew[0] == '2') : RT_LDSW_DEFAULT != 0;
+            LdswBuild wb;
+            if (want_w && ks->ldsw.closest && !getenv("RT_HIP_SHADOW_RAYS") && !getenv("RT_HIP_PERSISTENT") && !getenv("RT_HIP_PERSISTENT_SHADOW") && build_ldsw(bvh.nodes, wb)) {
+                const size_t node_bytes = wb.nodes.size(), any_bytes = node_bytes + no * 16, all_bytes = (any_bytes + no * LDSW_BOX_BYTES + 15) & ~(size_t)15;
+                const size_t need_c = all_bytes + (size_t)(wb.levels + 1) * LDSW_BLOCK_CLOSEST * sizeof(LdswEntry), need_a = any_bytes + (size_t)(wb.levels + 1) * LDS_BLOCK_SHADOW * sizeof(LdswEntry);
+                if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: %d-wide LDS tree: %u nodes, %u levels, %zu B for closest-hit kernels, %zu B for any-hit kernels\n", LDSW, wb.n_nodes, wb.levels, need_c, need_a);
+                if (std::max(need_c, need_a) <= LDS_TREE_CAP) {
+                    std::vector<unsigned char> wimg(all_bytes, 0);
+                    memcpy(wimg.data(), wb.nodes.data(), node_bytes);
+                    float4* wsp = (float4*)(wimg.data() + node_bytes);
+                    float* wbx = (float*)(wimg.data() + any_bytes);
+                    for (size_t i = 0; i < no; i++) {
+                        if (d->objects[i].type == RT_HIT_SPHERE) wsp[i] = spheres[d->objects[i].index];
+                        for (int a = 0; a < 3; a++) { wbx[6 * i + a] = d->objects[i].aabb_min[a]; wbx[6 * i + 3 + a] = d->objects[i].aabb_max[a]; }
+                    }
+                    if ((rc = upload(s->ldsw_image, wimg))) return rc;
+                    sd.ldsw_image = s->ldsw_image.as<uint4>(); sd.ldsw_node_bytes = (uint32_t)node_bytes; sd.ldsw_any_bytes = (uint32_t)any_bytes; sd.ldsw_all_bytes = (uint32_t)all_bytes;
+                    sd.ldsw_axis_a = wb.axis_a; sd.ldsw_axis_b = wb.axis_b;
+                    s->use_ldsw = true; s->use_ldsw_closest = ew && ew[0] == '2'; s->ldsw_count = wb.n_nodes; s->ldsw_levels = wb.levels;
+                }
+            }
         }
     }
     // The 8-wide tree with quantised inner boxes (rt_wide.h, rt_wide.hip) for trees that are read through the caches: a third of the
@@ -630,7 +818,7 @@ int rt_scene_get_info(rt_scene* s, rt_scene_info* out) {
     out->n_objects = s->n_objects; out->n_unbounded = s->dev.n_unbounded; out->n_nodes = s->dev.n_nodes; out->bvh_depth = s->bvh_depth;
     out->tree_in_lds = s->use_lds ? 1u : 0u; out->lds_image_bytes = s->dev.lds_image_bytes;
     out->built_on_device = s->device_build ? 1u : 0u; out->object_list = s->dev.n_list_pairs ? 1u : 0u;
-    out->wide_nodes = s->use_wide ? s->wide_count : 0u; out->wide_levels = s->use_wide ? s->wide_levels : 0u; out->device = s->device;
+    out->wide_nodes = s->use_wide ? s->wide_count : s->use_ldsw ? s->ldsw_count : 0u; out->wide_levels = s->use_wide ? s->wide_levels : s->use_ldsw ? s->ldsw_levels : 0u; out->device = s->device;
     strncpy(out->variant, s->ks->name, sizeof(out->variant) - 1);
     return RT_OK;
 }
@@ -653,7 +841,7 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     (void)scratch_for_device(device);      // (best effort, as in rt_scene_create)
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
-    s->use_lds = src->use_lds; s->use_wide = src->use_wide; s->wide_count = src->wide_count; s->wide_levels = src->wide_levels; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
+    s->use_lds = src->use_lds; s->use_ldsw = src->use_ldsw; s->use_ldsw_closest = src->use_ldsw_closest; s->ldsw_count = src->ldsw_count; s->ldsw_levels = src->ldsw_levels; s->use_wide = src->use_wide; s->wide_count = src->wide_count; s->wide_levels = src->wide_levels; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
     s->n_objects = src->n_objects; s->n_lights = src->n_lights;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -677,14 +865,20 @@ static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t block
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
 static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * (s->use_wide ? sizeof(uint2) : sizeof(int)); }
-static inline size_t lds_tree_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
+// dynamic LDS of a kernel that holds the tree: the image and the lanes' stack columns.  closest: the W-wide form also carries the objects' exact boxes
+static inline size_t lds_binary_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
+static inline size_t lds_tree_bytes(const rt_scene* s, int block, bool closest) {
+    if (closest ? s->use_ldsw_closest : s->use_ldsw) return (closest ? s->dev.ldsw_all_bytes : s->dev.ldsw_any_bytes) + (size_t)(s->ldsw_levels + 1) * block * sizeof(LdswEntry);
+    return lds_binary_bytes(s, block);
+}
 static inline uint32_t lds_grid_for(const rt_scene* s, uint64_t work, int block, size_t lds_bytes) {
     uint64_t need = (work + block - 1) / block;
     uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds_bytes);
     per_cu = std::min<uint64_t>(per_cu, 2048 / block);
     return (uint32_t)std::max<uint64_t>(1, std::min(need, (uint64_t)s->n_cu * per_cu));
 }
-static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block) { return lds_grid_for(s, work, block, lds_tree_bytes(s, block)); }
+static inline int closest_block(const rt_scene* s) { return s->use_ldsw_closest ? LDSW_BLOCK_CLOSEST : LDS_BLOCK_CLOSEST; }
+static inline uint32_t lds_grid(const rt_scene* s, uint64_t work, int block, bool closest) { return lds_grid_for(s, work, block, lds_tree_bytes(s, block, closest)); }
 
 // -------------------------------------------------------------------------------------------------
 // Parity hooks
@@ -711,7 +905,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, float k_min, f
     if (int rc = trace_staging(s->trace_out, n * sizeof(rt_hit))) return rc;
     rt_ray* dr = s->trace_in.as<rt_ray>(); rt_hit* dh = s->trace_out.as<rt_hit>();
     HIP_TRY(hipMemcpy(dr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, dr, n, k_min, k_max, seed, dh);
+    if (s->use_lds) hipLaunchKernelGGL(s->use_ldsw_closest ? s->ks->ldsw.trace_closest : s->ks->trace_closest_lds, dim3(lds_grid(s, n, closest_block(s), true)), dim3(closest_block(s)), lds_tree_bytes(s, closest_block(s), true), 0, s->dev, dr, n, k_min, k_max, seed, dh);
     else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_closest : s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, n, k_min, k_max, seed, dh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hits, dh, n * sizeof(rt_hit), hipMemcpyDeviceToHost));           // (null stream: ordered after the kernel, blocks until the copy is done)
@@ -731,7 +925,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipMemcpy(dr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d0, k_min, n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d1, k_max, n * sizeof(float), hipMemcpyHostToDevice));
-    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), 0, s->dev, dr, d0, d1, n, dout);
+    if (s->use_lds) hipLaunchKernelGGL(s->use_ldsw ? s->ks->ldsw.trace_any : s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), 0, s->dev, dr, d0, d1, n, dout);
     else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_any : s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, dout, n, hipMemcpyDeviceToHost));
@@ -746,16 +940,18 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, uint64_t n, float 
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(RT_ERR_HIP, "cannot select device %d", s->device);
     if (int rc = scratch_for_device(s->device)) return rc;      // normally resolved by rt_scene_create already; hipGetSymbolAddress allocates nothing
-    void* base = nullptr;
-    { std::lock_guard<std::mutex> lock(g_scratch_mutex); base = g_scratch[s->device]; }
-    // [rays: MAX x rt_ray][hits: MAX x rt_hit]; every hit record of 0..n-1 is written by the kernel, nothing has to start at zero
+    void* base = nullptr; hipStream_t st = nullptr;
+    { std::lock_guard<std::mutex> lock(g_scratch_mutex); base = g_scratch[s->device]; st = g_scratch_stream[s->device]; }
+    // [rays: MAX x rt_ray][hits: MAX x rt_hit]; every hit record of 0..n-1 is written by the kernel, nothing has to start at zero.
+    // Copies and launch go to the device's own non-blocking stream: the call neither waits for nor orders itself against the null stream.
     rt_ray* d_rays = (rt_ray*)base;
     rt_hit* d_hits = (rt_hit*)((unsigned char*)base + (size_t)RT_TRACE_NOALLOC_MAX_RAYS * sizeof(rt_ray));
-    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    if (s->use_lds) hipLaunchKernelGGL(s->ks->trace_closest_lds, dim3(lds_grid(s, n, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
-    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_closest : s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+    if (s->use_lds) hipLaunchKernelGGL(s->use_ldsw_closest ? s->ks->ldsw.trace_closest : s->ks->trace_closest_lds, dim3(lds_grid(s, n, closest_block(s), true)), dim3(closest_block(s)), lds_tree_bytes(s, closest_block(s), true), st, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
+    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_closest : s->ks->trace_closest, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), st, s->dev, d_rays, n, k_min, k_max, seed, d_hits);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost));       // (null stream: ordered after the kernel, blocks until the copy is done)
+    HIP_TRY(hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
 }
 
@@ -1005,14 +1201,16 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
         { Timed t(r, RT_K_CLOSEST, st);
           const bool prim = rd.implicit_primary && depth == 0;
-          if (s->use_lds) hipLaunchKernelGGL(prim ? ks->closest_primary_lds : ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST), st, s->dev, rd, depth);
+          if (s->use_ldsw_closest) hipLaunchKernelGGL(prim ? ks->ldsw.closest_primary : ks->ldsw.closest, dim3(lds_grid(s, rd.n_paths, LDSW_BLOCK_CLOSEST, true)), dim3(LDSW_BLOCK_CLOSEST), lds_tree_bytes(s, LDSW_BLOCK_CLOSEST, true), st, s->dev, rd, depth);
+          else if (s->use_lds) hipLaunchKernelGGL(prim ? ks->closest_primary_lds : ks->closest_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_CLOSEST, true)), dim3(LDS_BLOCK_CLOSEST), lds_tree_bytes(s, LDS_BLOCK_CLOSEST, true), st, s->dev, rd, depth);
           else if (s->use_wide) hipLaunchKernelGGL(prim ? ks->wide.closest_primary : s->persistent && depth > 0 ? ks->wide.closest_persistent : ks->wide.closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else hipLaunchKernelGGL(prim ? ks->closest_primary : s->persistent && depth > 0 ? ks->closest_persistent : ks->closest, dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), rd.obj_shade_lds_bytes, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
-          if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_tree_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_tree_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
+          if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_binary_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_binary_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
           else if (ray_lanes) hipLaunchKernelGGL(s->use_wide ? (ex ? ks->wide.shadow_rays_exact : ks->wide.shadow_rays) : (ex ? ks->shadow_rays_exact : ks->shadow_rays), dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
-          else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW), st, s->dev, rd, depth);
+          else if (s->use_ldsw) hipLaunchKernelGGL(ex ? ks->ldsw.shadow_exact : ks->ldsw.shadow, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
+          else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
           else if (s->use_wide) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->wide.shadow_persistent_exact : ks->wide.shadow_persistent) : (ex ? ks->wide.shadow_exact : ks->wide.shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }

@@ -64,7 +64,7 @@ RT_FN WideRay wide_ray_closest(const SceneDev& sc, const Ray& r, f3 inv_exact) {
     return make_wide_ray(r, inv_exact, (1e-6f * far_side) + 1e-30f, WIDE_INV_LIMIT * __builtin_amdgcn_rsqf(dot(r.d, r.d)));
 }
 // Any hit: the pad of any_box (rt_device.h) — two looks, first with none.
-RT_FN WideRay wide_ray_any(const SceneDev& sc, const Ray& r, float kMax, float cap, int mode, bool& again) {
+RT_FN WideRay wide_ray_any(const SceneDev& sc, const WideTree&, const Ray& r, float kMax, float cap, int mode, bool& again) {
     const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
     const float len = __builtin_amdgcn_sqrtf(dot(r.d, r.d));
     const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;

@@ -118,3 +118,44 @@ def test_every_kernel_that_walks_the_wide_tree(env, monkeypatch):
         st = job.RenderStats; out.append((job.ReadAccum()[0], st.RayCount, st.ShadowRays)); job.Dispose()
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
     wide.Dispose(); binary.Dispose()
+
+
+@pytest.mark.parametrize("name", ["Testing", "RtInAWeekendCover1"])
+def test_lds_wide_tree_against_the_binary_lds_tree(name, monkeypatch):
+    """Small all-sphere scenes keep their tree in LDS in two forms (rt_ldsw.h): the binary one and a 4-wide one whose inner boxes are only
+    conservative.  RT_HIP_LDS_WIDE=0 walks the binary form everywhere, =1 (the default) gives the any-hit kernels the wide form, =2 the
+    closest-hit kernels too: same hits (K bits included), same any-hit answers, same pictures bit for bit, same ray counts."""
+    sc = helpers.small_scenes()[name](); flat = flatten_scene(sc)
+    devs = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("RT_HIP_LDS_WIDE", mode); devs[mode] = rt.DeviceScene(flat)
+    monkeypatch.delenv("RT_HIP_LDS_WIDE")
+    assert all(d.Info()["tree_in_lds"] for d in devs.values())
+    assert devs["0"].Info()["wide_nodes"] == 0 and devs["1"].Info()["wide_nodes"] >= 1 and devs["2"].Info()["wide_nodes"] == devs["1"].Info()["wide_nodes"]
+    assert rt.DeviceScene(flat).Info()["wide_nodes"] == devs["1"].Info()["wide_nodes"]              # the default is mode 1
+    orc = ob.OracleScene(flat)
+    rs = np.random.default_rng(6)
+    o1, d1 = helpers.camera_rays(sc, 64, 64, 50_000, rs); o2, d2 = helpers.secondary_rays(flat, 50_000, rs)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    o[:200] = o[200:400] * np.array([1, 0, 1], np.float32) + np.array([0, 9, 0], np.float32); d[:200] = np.array([0, -1, 0], np.float32)      # axis-parallel rays: 1/d infinite on two axes
+    base = devs["0"].TraceClosest(o, d, 0.001, np.inf, seed=1)
+    for mode in ("1", "2"):
+        _same_hits(devs[mode].TraceClosest(o, d, 0.001, np.inf, seed=1), base, flat, (o, d))
+    so, sd, kmin, kmax = helpers.shadow_ray_set(sc, flat, orc, 100_000, 3)
+    ref = orc.trace_any(so, sd, kmin, kmax).astype(bool)                                            # = the reference's every-object scan
+    for mode, dev in devs.items():
+        assert np.array_equal(dev.TraceAny(so, sd, kmin, kmax).astype(bool), ref), mode
+    for kw in (dict(), dict(ExactLightSampling=True, ExactOcclusion=True)):
+        opt = RenderOptions(RenderWidth=160, RenderHeight=90, Passes=3, MaxBounceDepth=8, Seed=4, **kw)
+        out = {}
+        for mode, dev in devs.items():
+            job = rt.RenderJob(sc, opt, device_scene=dev); job.Wait()
+            st = job.RenderStats; out[mode] = (job.ReadAccum()[0], st.RayCount, st.ShadowRays, st.PixelsRendered); job.Dispose()
+        for mode in ("1", "2"):
+            same = (out[mode][0] == out["0"][0]) | (np.isnan(out[mode][0]) & np.isnan(out["0"][0]))
+            # exact occlusion: every answer is the scan's, so not a bit differs; default occlusion caps the pad, and which far-away noise hits
+            # are still found depends on the boxes (Night Spheres: none within reach, so still the same bits)
+            assert same.all(axis=2).mean() >= (1.0 if kw else 0.9995), (name, mode, kw, same.all(axis=2).mean())
+            assert out[mode][1:] == out["0"][1:]
+    for dev in devs.values():
+        dev.Dispose()
