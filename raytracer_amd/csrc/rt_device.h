@@ -137,6 +137,8 @@ struct SceneDev {
     const uint4* ldsw_image;     uint32_t ldsw_node_bytes;   // nodes, then spheres[n_objects], then boxes[n_objects] (2 x float4 each)
     uint32_t ldsw_any_bytes, ldsw_all_bytes;                 // what an any-hit kernel copies (nodes + spheres) / a closest-hit kernel (+ boxes)
     uint32_t ldsw_axis_a, ldsw_axis_b;                       // W = 4: the two axes the quadrant slots are laid out along
+    // all-sphere trees that are read through the caches: the same W-wide form for their any-hit kernels (QuadTree, rt_ldsw.h), null otherwise
+    const uint4* quad_image;     uint32_t quad_node_bytes;   // nodes, then spheres[n_objects], then boxes[n_objects]
 };
 
 struct Ray { f3 o, d; };

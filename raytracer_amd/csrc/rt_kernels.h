@@ -224,7 +224,7 @@ constexpr int lds_block_closest(int tree) { return tree == 3 ? LDSW_BLOCK_CLOSES
 #endif
 constexpr int LDS_BLOCK_RAYS = RT_LDS_BLOCK_RAYS;      // k_shadow_rays with the tree in LDS: 81 VGPRs let 6 waves/SIMD in, two blocks of 12 waves per CU
 // where a traversal kernel reads the tree from: the binary tree through the caches, the binary tree in LDS, the 8-wide tree through the caches
-enum : int { TREE_HBM = 0, TREE_LDS = 1, TREE_WIDE = 2, TREE_LDSW = 3 };      // LDSW: the W-wide tree in LDS (rt_ldsw.h)
+enum : int { TREE_HBM = 0, TREE_LDS = 1, TREE_WIDE = 2, TREE_LDSW = 3, TREE_QUAD = 4 };      // LDSW: the W-wide float tree in LDS, QUAD: the same read through the caches (rt_ldsw.h)
 constexpr bool tree_in_lds(int tree) { return tree == TREE_LDS || tree == TREE_LDSW; }
 template <int TREE, int TB, bool CLOSEST = true>
 RT_FN auto make_tree(const SceneDev& sc) {
@@ -234,6 +234,8 @@ RT_FN auto make_tree(const SceneDev& sc) {
         for (uint32_t i = threadIdx.x; i < bytes / 16; i += TB) dst[i] = sc.ldsw_image[i];
         __syncthreads();
         return LdswTree::carve(lds_stack, sc.ldsw_node_bytes, sc.n_objects, bytes, (int)threadIdx.x, TB);
+    } else if constexpr (TREE == TREE_QUAD) {
+        return QuadTree::global(sc.quad_image, sc.quad_node_bytes, sc.n_objects, lds_stack, (int)threadIdx.x, TB);
     } else if constexpr (TREE == TREE_WIDE) {
         WideTree t; t.stack = (uint2*)lds_stack + threadIdx.x; t.stride = TB;
         return t;
@@ -844,9 +846,12 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_RAYS : BLOCK, TRE
 // 5 waves instead of 4 and 33.5 -> 36.8 Msamples/s on the 100 k spheres + 64 lights scene; the others would only spill)
 template <class C> struct ShadowPersistentTune { static constexpr int min_waves = 1; };
 template <class C> struct ShadowPersistentWideTune { static constexpr int min_waves = 1; };
+#ifndef RT_SPQ_WAVES
+#define RT_SPQ_WAVES 1
+#endif
 template <class C, int TREE, bool EXACT = false>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_WIDE ? ShadowPersistentWideTune<C>::min_waves : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
-    constexpr bool WIDE = TREE == TREE_WIDE;
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_QUAD ? RT_SPQ_WAVES : TREE == TREE_WIDE ? ShadowPersistentWideTune<C>::min_waves : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+    constexpr bool WIDE = TREE == TREE_WIDE || TREE == TREE_QUAD;
     constexpr int TB = TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK;
     const auto tree = make_tree<TREE, TB>(sc);
     const uint32_t n = rd.sqcount[depth];
@@ -872,7 +877,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
     uint32_t unused = 0;
     float kMin = 0, kMax = 0;
     int cur = TRAV_DONE, pend = TRAV_DONE; Stk sp = stk_empty();
-    WideRay wr = make_wide_ray(r, mk3(0, 0, 1), 0.0f, 1.0f); WideCursor wc = wide_idle();      // the wide tree
+    auto wr = [&] { if constexpr (WIDE) return wide_ray_idle(tree); else return 0; }(); WideCursor wc = wide_idle();      // the wide trees
     auto lane_busy = [&]() { if constexpr (WIDE) return wide_busy(wc); else return cur != TRAV_DONE || pend != TRAV_DONE; };
     int spins = 0;
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
@@ -971,7 +976,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
                 while (wide_vote(wc)) if (wide_can_step(wc)) nodes += wide_step(sc, tree, wr, kMin, kMax, wc);
                 if (wide_has_leaf(wc)) {
                     prims++;
-                    if (wide_leaf_any<C>(sc, wide_take_leaf(wc, wr), r, kMin, kMax)) { occluded = true; wide_stop(wc); }
+                    if (wide_next_leaf_any<C>(sc, tree, wc, wr, r, kMin, kMax)) { occluded = true; wide_stop(wc); }
                 }
             } else {
                 while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
@@ -1135,6 +1140,16 @@ struct KernelSet {
         void (*trace_closest)(SceneDev, const rt_ray*, uint64_t, float, float, uint64_t, rt_hit*);
         void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
     } ldsw;
+    // the any-hit kernels over the W-wide float tree read through the caches (QuadTree, rt_ldsw.h; null when the variant knows no spheres)
+    struct Quad {
+        void (*shadow)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_exact)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_rays)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_rays_exact)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_persistent)(SceneDev, RenderDev, uint32_t);
+        void (*shadow_persistent_exact)(SceneDev, RenderDev, uint32_t);
+        void (*trace_any)(SceneDev, const rt_ray*, const float*, const float*, uint64_t, uint8_t*);
+    } quad;
 };
 template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char* name) {
     KernelSet k{name, C::prims, C::mats, C::texs, C::lights, k_closest<C, false>, k_shade<C>, k_shadow<C, false>, k_trace_closest<C, false>, k_trace_any<C, false>,
@@ -1143,6 +1158,7 @@ template <class C, bool WITH_LDS> constexpr KernelSet make_kernel_set(const char
                 {k_closest<C, TREE_WIDE>, k_closest<C, TREE_WIDE, true>, k_closest_persistent<C, TREE_WIDE>, k_shadow<C, TREE_WIDE>, k_shadow<C, TREE_WIDE, true>, k_shadow_rays<C, TREE_WIDE>, k_shadow_rays<C, TREE_WIDE, true>,
                  k_shadow_persistent<C, TREE_WIDE>, k_shadow_persistent<C, TREE_WIDE, true>, k_trace_closest<C, TREE_WIDE>, k_trace_any<C, TREE_WIDE>}};
     if constexpr (WITH_LDS) { k.closest_lds = k_closest<C, true>; k.closest_primary_lds = k_closest<C, true, true>; k.shadow_lds = k_shadow<C, true>; k.shadow_rays_lds = k_shadow_rays<C, true>; k.shadow_rays_lds_exact = k_shadow_rays<C, true, true>; k.shadow_lds_exact = k_shadow<C, true, true>; k.trace_closest_lds = k_trace_closest<C, true>; k.trace_any_lds = k_trace_any<C, true>;
+                               k.quad = {k_shadow<C, TREE_QUAD>, k_shadow<C, TREE_QUAD, true>, k_shadow_rays<C, TREE_QUAD>, k_shadow_rays<C, TREE_QUAD, true>, k_shadow_persistent<C, TREE_QUAD>, k_shadow_persistent<C, TREE_QUAD, true>, k_trace_any<C, TREE_QUAD>};
                                k.ldsw = {k_closest<C, TREE_LDSW>, k_closest<C, TREE_LDSW, true>, k_shadow<C, TREE_LDSW>, k_shadow<C, TREE_LDSW, true>, k_trace_closest<C, TREE_LDSW>, k_trace_any<C, TREE_LDSW>}; }
     return k;
 }

@@ -11,9 +11,10 @@
 //
 // LDS image (rt_lib.hip: build_ldsw writes it; every workgroup copies it):
 //   nodes[n]      LDSW_NODE_BYTES each:
-//                   +0   u32  child_base (the first inner child's offset in 16-B units) | imask << 16 | lmask << 24      which slots hold an inner node / a leaf
-//                   +16  u16 x W  object id of the leaf in each slot
-//                   +32  per axis (x, y, z) 3 W floats: min[W] max[W] min[W] — the repeated min block turns the ray's sign into a byte
+//                   +0   u32  child_base: the first inner child's offset in 16-B units
+//                   +4   u32  imask | lmask << 8      which slots hold an inner node / a leaf
+//                   +16  u32 x W  object id of the leaf in each slot
+//                   +16 + 4 W  per axis (x, y, z) 3 W floats: min[W] max[W] min[W] — the repeated min block turns the ray's sign into a byte
 //                        offset: read at +0 (near, far) = (min, max) for a ray along +axis, at +4W bytes (max, min) along -axis
 //                 the k-th inner child (slots ascending) is the record at child_base + k * LDSW_NODE_UNITS
 //   spheres[n_objects]   float4 by object id
@@ -21,6 +22,7 @@
 // Slots are assigned by quadrant / octant (Ylitie, Karras, Laine 2017; W = 4: by the two axes along which the scene is largest), so
 // visiting the hit slots by descending (slot XOR octinv) is front to back with no sorting.
 #pragma once
+#include <type_traits>
 #include "rt_wide.h"
 
 namespace rtd {
@@ -31,32 +33,54 @@ namespace rtd {
 #ifndef RT_LDSW_DEFAULT
 #define RT_LDSW_DEFAULT 1          // 1: the any-hit kernels of scenes whose tree fits LDS in both forms walk the W-wide one unless RT_HIP_LDS_WIDE=0 (=2: the closest-hit kernels too)
 #endif
+#ifndef RT_QUAD_ORDERED
+#define RT_QUAD_ORDERED 1           // any-hit rays enter a node's children front to back in trees read through the caches (an occluder near the origin ends the ray at once), in slot order in LDS
+#endif
 constexpr int LDSW = RT_LDSW;
-static_assert(LDSW == 4 || LDSW == 8, "slots per node of the LDS wide tree");
-constexpr uint32_t LDSW_AXIS_BYTES = 12u * LDSW, LDSW_HEAD_BYTES = 32u, LDSW_NODE_BYTES = LDSW_HEAD_BYTES + 3u * LDSW_AXIS_BYTES, LDSW_NODE_UNITS = LDSW_NODE_BYTES / 16u;
+static_assert(LDSW == 4 || LDSW == 8, "slots per node of the W-wide float tree");
+constexpr uint32_t LDSW_AXIS_BYTES = 12u * LDSW, LDSW_HEAD_BYTES = 16u + 4u * LDSW, LDSW_NODE_BYTES = LDSW_HEAD_BYTES + 3u * LDSW_AXIS_BYTES, LDSW_NODE_UNITS = LDSW_NODE_BYTES / 16u;
 constexpr uint32_t LDSW_BOX_BYTES = 24u;
-// a stack entry = a group: first node | (hits | imask << 8) << 16
-constexpr uint32_t LDSW_MAX_NODES = 65536u / LDSW_NODE_UNITS;      // (a node is named by its offset in 16-B units, in 16 bits)
-typedef uint32_t LdswEntry;
-RT_FN LdswEntry ldsw_pack(uint32_t gbase, uint32_t gbits) { return gbase | (gbits << 16); }
-RT_FN void ldsw_unpack(uint32_t e, uint32_t& gbase, uint32_t& gbits) { gbase = e & 0xFFFFu; gbits = e >> 16; }
+constexpr uint32_t LDSW_MAX_NODES_LDS = 65536u / LDSW_NODE_UNITS;      // in LDS a node is named by its offset in 16-B units in 16 bits (a stack entry is 32 bits)
 
-struct LdswTree {
+// BIG = false: the image lives in LDS (every workgroup copies it), a stack entry packs group base (16 bits) | hits | imask into 32 bits, lanes
+//       step until they hold a leaf (rays of about equal cost: no votes, as for LdsTree).
+// BIG = true:  the image is read through the caches (trees of up to 2^28 nodes), a stack entry is 64 bits, the wave votes as for WideTree.
+template <bool BIG>
+struct LdswTreeT {
     static constexpr bool wide = true;
     static constexpr bool list = false;
+    static constexpr bool vote = BIG;
+    typedef typename std::conditional<BIG, uint2, uint32_t>::type Entry;
     const char* nodes; const float4* sph; const float2* boxes;
-    LdswEntry* stack; int stride;                // this lane's column of group entries (ldsw_pack)
-    RT_FN void push(int sp, LdswEntry v) const { stack[sp * stride] = v; }
-    RT_FN uint32_t pop(int sp) const { return stack[sp * stride]; }
-    RT_FN static LdswTree carve(const void* base, uint32_t node_bytes, uint32_t n_objects, uint32_t copied_bytes, int tid, int block) {
-        LdswTree t;
+    Entry* stack; int stride;                    // this lane's column of group entries
+    RT_FN void push(int sp, uint32_t gbase, uint32_t gbits) const {
+        if constexpr (BIG) stack[sp * stride] = make_uint2(gbase, gbits); else stack[sp * stride] = gbase | (gbits << 16);
+    }
+    RT_FN void pop(int sp, uint32_t& gbase, uint32_t& gbits) const {
+        if constexpr (BIG) { const uint2 e = stack[sp * stride]; gbase = e.x; gbits = e.y; } else { const uint32_t e = stack[sp * stride]; gbase = e & 0xFFFFu; gbits = e >> 16; }
+    }
+    // LDS: carve the copied image into its tables, the stack columns behind it
+    RT_FN static LdswTreeT carve(const void* base, uint32_t node_bytes, uint32_t n_objects, uint32_t copied_bytes, int tid, int block) {
+        LdswTreeT t;
         t.nodes = (const char*)base;
         t.sph = (const float4*)((const char*)base + node_bytes);
         t.boxes = (const float2*)(t.sph + n_objects);
-        t.stack = (LdswEntry*)((const char*)base + copied_bytes) + tid; t.stride = block;
+        t.stack = (Entry*)((const char*)base + copied_bytes) + tid; t.stride = block;
+        return t;
+    }
+    // read through the caches: the image stays where it is, the stack columns are the workgroup's dynamic LDS
+    RT_FN static LdswTreeT global(const void* image, uint32_t node_bytes, uint32_t n_objects, void* lds, int tid, int block) {
+        LdswTreeT t;
+        t.nodes = (const char*)image;
+        t.sph = (const float4*)((const char*)image + node_bytes);
+        t.boxes = (const float2*)(t.sph + n_objects);
+        t.stack = (Entry*)lds + tid; t.stride = block;
         return t;
     }
 };
+typedef LdswTreeT<false> LdswTree;
+typedef LdswTreeT<true> QuadTree;
+typedef uint32_t LdswEntry;
 
 // what a node visit needs of the ray: per axis 1/d (clamped), the two addends of the near and the far plane, the byte offset of the near block
 // ORDERED: the hit slots of a node are entered front to back (closest hit).  Any-hit rays enter them in slot order: in a tree this small
@@ -92,7 +116,8 @@ RT_FN LdswRay ldsw_ray_closest(const SceneDev& sc, const Ray& r, f3 inv_exact) {
     return make_ldsw_ray<true>(sc, r, inv_exact, (1e-6f * far_side) + 1e-30f, WIDE_INV_LIMIT * __builtin_amdgcn_rsqf(dot(r.d, r.d)));
 }
 // Any hit: the pad of any_box (rt_device.h) — two looks, first with none.
-RT_FN LdswRay wide_ray_any(const SceneDev& sc, const LdswTree&, const Ray& r, float kMax, float cap, int mode, bool& again) {
+template <bool BIG>
+RT_FN LdswRay wide_ray_any(const SceneDev& sc, const LdswTreeT<BIG>&, const Ray& r, float kMax, float cap, int mode, bool& again) {
     const f3 c = mk3(sc.bounds_centre[0], sc.bounds_centre[1], sc.bounds_centre[2]);
     const float len = __builtin_amdgcn_sqrtf(dot(r.d, r.d));
     const float far_side = __builtin_amdgcn_sqrtf(distance_sq(r.o, c)) + sc.bounds_radius;
@@ -106,8 +131,8 @@ RT_FN LdswRay wide_ray_any(const SceneDev& sc, const LdswTree&, const Ray& r, fl
     again = mode == 0 && round > (sc.any_again * rm);
     const f3 inv = mk3(rcp_fast(r.d.x), rcp_fast(r.d.y), rcp_fast(r.d.z));
     const float lim = WIDE_INV_LIMIT * rcp_fast(len);
-    if (again) return make_ldsw_ray<false>(sc, r, inv, 0.0f, lim);
-    return make_ldsw_ray<false>(sc, r, inv, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))), lim);
+    if (again) return make_ldsw_ray<BIG && RT_QUAD_ORDERED>(sc, r, inv, 0.0f, lim);
+    return make_ldsw_ray<BIG && RT_QUAD_ORDERED>(sc, r, inv, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)))), lim);
 }
 
 RT_FN uint32_t xor_permute_w(uint32_t m, uint32_t x) {      // position p of a W-bit mask -> position p ^ x
@@ -117,10 +142,11 @@ RT_FN uint32_t xor_permute_w(uint32_t m, uint32_t x) {      // position p of a W
     return m;
 }
 
-// One node: which of its W child boxes the ray's [kMin, kMax] meets (slot order).  `head` returns the node's first word.
-RT_FN uint32_t ldsw_visit(const LdswTree& t, const LdswRay& q, uint32_t node, float kMin, float kMax, uint32_t& head) {
-    const char* n = t.nodes + (node << 4);
-    head = *(const uint32_t*)n;
+// One node: which of its W child boxes the ray's [kMin, kMax] meets (slot order).  `head` returns the node's first two words.
+template <bool BIG>
+RT_FN uint32_t ldsw_visit(const LdswTreeT<BIG>& t, const LdswRay& q, uint32_t node, float kMin, float kMax, uint2& head) {
+    const char* n = t.nodes + ((size_t)node << 4);
+    head = *(const uint2*)n;
     const char* ax = n + LDSW_HEAD_BYTES + q.ox;
     const char* ay = n + LDSW_HEAD_BYTES + LDSW_AXIS_BYTES + q.oy;
     const char* az = n + LDSW_HEAD_BYTES + 2u * LDSW_AXIS_BYTES + q.oz;
@@ -156,42 +182,43 @@ RT_FN uint32_t ldsw_visit(const LdswTree& t, const LdswRay& q, uint32_t node, fl
 RT_FN WideCursor ldsw_start(const LdswRay& q) { WideCursor c = wide_idle(); c.gbits = (1u << q.octinv) | (1u << 8); return c; }      // the root as a one-child group: node 0 in slot 0
 
 // Enter the next child still in G (ORDERED: the nearest) and test its children.  Returns the number of boxes tested.
-template <bool ORDERED>
-RT_FN uint32_t ldsw_step(const LdswTree& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) {
+template <bool ORDERED, bool BIG>
+RT_FN uint32_t ldsw_step(const LdswTreeT<BIG>& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) {
     const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.gbits & 0xFFu);
     const uint32_t slot = ORDERED ? pi ^ q.octinv : pi, gmask = (c.gbits >> 8) & 0xFFu;
     const uint32_t node = c.gbase + __umul24((uint32_t)__builtin_popcount(gmask & ((1u << slot) - 1u)), LDSW_NODE_UNITS);
     const uint32_t rest = c.gbits & ~(1u << pi);                 // the siblings still to enter
-    uint32_t head;
+    uint2 head;
     const uint32_t hits = ldsw_visit(tree, q, node, kMin, kMax, head);
-    const uint32_t imask = (head >> 16) & 0xFFu, lmask = head >> 24;
+    const uint32_t imask = head.y & 0xFFu, lmask = (head.y >> 8) & 0xFFu;
     c.pbase = node; c.pbits = (ORDERED ? xor_permute_w(hits & lmask, q.octinv) : hits & lmask) | (lmask << 8);
     const uint32_t inner = hits & imask;
     if (inner) {                                                  // descend: the siblings wait in the lane's column
-        if (rest & 0xFFu) { tree.push(c.sp, ldsw_pack(c.gbase, rest)); c.sp++; }
-        c.gbase = head & 0xFFFFu; c.gbits = (ORDERED ? xor_permute_w(inner, q.octinv) : inner) | (imask << 8);
+        if (rest & 0xFFu) { tree.push(c.sp, c.gbase, rest); c.sp++; }
+        c.gbase = head.x; c.gbits = (ORDERED ? xor_permute_w(inner, q.octinv) : inner) | (imask << 8);
     } else if (rest & 0xFFu) c.gbits = rest;                      // nothing below: on with the siblings
-    else if (c.sp) { c.sp--; ldsw_unpack(tree.pop(c.sp), c.gbase, c.gbits); }
+    else if (c.sp) { c.sp--; tree.pop(c.sp, c.gbase, c.gbits); }
     else c.gbits = 0;
     return (uint32_t)__builtin_popcount(imask | lmask);
 }
 // the next leaf of P: its object id
-template <bool ORDERED>
-RT_FN uint32_t ldsw_take_leaf(const LdswTree& tree, WideCursor& c, const LdswRay& q) {
+template <bool ORDERED, bool BIG>
+RT_FN uint32_t ldsw_take_leaf(const LdswTreeT<BIG>& tree, WideCursor& c, const LdswRay& q) {
     const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.pbits & 0xFFu);
     const uint32_t slot = ORDERED ? pi ^ q.octinv : pi;
     c.pbits &= ~(1u << pi);
-    return *(const unsigned short*)(tree.nodes + (c.pbase << 4) + 16u + 2u * slot);
+    return *(const uint32_t*)(tree.nodes + ((size_t)c.pbase << 4) + 16u + 4u * slot);
 }
 
 // the tree part of closest_hit (rt_device.h).  Lanes step until they hold a leaf (rays of about equal cost: no votes, as for LdsTree).
-template <class C>
-RT_FN void closest_wide(const SceneDev& sc, const LdswTree& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt) {
+template <class C, bool BIG>
+RT_FN void closest_wide(const SceneDev& sc, const LdswTreeT<BIG>& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt) {
     const f3 inv = splat(1.0f) / r.d;
     const LdswRay q = ldsw_ray_closest(sc, r, inv);
     WideCursor c = ldsw_start(q);
     for (;;) {
-        while (wide_can_step(c)) cnt.nodes += ldsw_step<true>(tree, q, kMin, best.k, c);
+        if constexpr (BIG) { while (wide_vote(c)) if (wide_can_step(c)) cnt.nodes += ldsw_step<true>(tree, q, kMin, best.k, c); }
+        else while (wide_can_step(c)) cnt.nodes += ldsw_step<true>(tree, q, kMin, best.k, c);
         if (wide_has_leaf(c)) {
             // the object's own box first, in the reference's arithmetic (AxisAlignedBoundingBox.Hit through slab(): SingleObjectBvhNode.cs:12-16), then Hittable.TryHit
             const uint32_t obj = ldsw_take_leaf<true>(tree, c, q);
@@ -209,14 +236,23 @@ RT_FN void closest_wide(const SceneDev& sc, const LdswTree& tree, const Ray& r, 
     }
 }
 // the tree part of any_hit: one look with the pad of `q`.  Hittable.FastTryHit, no box test at the leaf (BinaryBvhNode.cs:41).
-template <class C>
-RT_FN bool any_wide(const SceneDev& sc, const LdswTree& tree, const LdswRay& q, const Ray& r, float kMin, float kMax, TravCount& cnt) {
+template <class C, bool BIG>
+RT_FN bool any_wide(const SceneDev& sc, const LdswTreeT<BIG>& tree, const LdswRay& q, const Ray& r, float kMin, float kMax, TravCount& cnt) {
     WideCursor c = ldsw_start(q);
     for (;;) {
-        while (wide_can_step(c)) cnt.nodes += ldsw_step<false>(tree, q, kMin, kMax, c);
-        if (wide_has_leaf(c)) { float k; cnt.prims++; if (try_sphere(tree.sph[ldsw_take_leaf<false>(tree, c, q)], r, kMin, kMax, k)) return true; }
+        if constexpr (BIG) { while (wide_vote(c)) if (wide_can_step(c)) cnt.nodes += ldsw_step<RT_QUAD_ORDERED>(tree, q, kMin, kMax, c); }
+        else while (wide_can_step(c)) cnt.nodes += ldsw_step<false>(tree, q, kMin, kMax, c);
+        if (wide_has_leaf(c)) { float k; cnt.prims++; if (try_sphere(tree.sph[ldsw_take_leaf<BIG && RT_QUAD_ORDERED>(tree, c, q)], r, kMin, kMax, k)) return true; }
         if (!wide_busy(c)) return false;
     }
+}
+
+// ---- the names k_shadow_persistent uses for either wide tree (rt_wide.h has the WideTree overloads)
+template <bool BIG> RT_FN LdswRay wide_ray_idle(const LdswTreeT<BIG>&) { LdswRay q; q.inv = mk3(0, 0, 1); q.an = mk3(0, 0, 0); q.af = mk3(0, 0, 0); q.ox = 0; q.oy = 0; q.oz = 0; q.octinv = 0; return q; }
+RT_FN WideCursor wide_start(const LdswRay& q) { return ldsw_start(q); }
+template <bool BIG> RT_FN uint32_t wide_step(const SceneDev&, const LdswTreeT<BIG>& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) { return ldsw_step<BIG && RT_QUAD_ORDERED>(tree, q, kMin, kMax, c); }
+template <class C, bool BIG> RT_FN bool wide_next_leaf_any(const SceneDev&, const LdswTreeT<BIG>& tree, WideCursor& c, const LdswRay& q, const Ray& r, float kMin, float kMax) {
+    float k; return try_sphere(tree.sph[ldsw_take_leaf<BIG && RT_QUAD_ORDERED>(tree, c, q)], r, kMin, kMax, k);
 }
 
 } // namespace rtd

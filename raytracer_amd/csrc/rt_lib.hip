@@ -83,7 +83,7 @@ constexpr int N_KERNEL_SETS = sizeof(g_kernel_sets) / sizeof(g_kernel_sets[0]);
 
 // every device buffer of a scene (X-macro: allocation, peer copy to a replica, pointer binding all walk the same list)
 #define RT_SCENE_BUFFERS(X) \
-    X(nodes) X(wide_nodes) X(wide_leaves) X(list_nodes) X(lds_image) X(ldsw_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
+    X(nodes) X(wide_nodes) X(wide_leaves) X(list_nodes) X(lds_image) X(ldsw_image) X(quad_image) X(obj_code) X(obj_material) X(obj_shade) X(unbounded) X(media) X(spheres) X(quads) X(triangles) X(inf_planes) \
     X(axis0) X(axis1) X(axis2) X(disks) X(boxes) X(capsules) X(cylinders) X(media_rec) X(materials) X(textures) X(lights)
 
 struct rt_scene {
@@ -96,6 +96,8 @@ struct rt_scene {
     bool use_ldsw = false;           // ... its any-hit kernels through the W-wide tree in LDS (rt_ldsw.h) instead of the binary one (use_lds stays set: everything else about "tree in LDS" holds)
     bool use_ldsw_closest = false;   // ... and its closest-hit kernels too (RT_HIP_LDS_WIDE=2)
     uint32_t ldsw_count = 0, ldsw_levels = 0;
+    bool use_quad = false;           // the any-hit kernels of a tree read through the caches walk its W-wide float form (QuadTree, rt_ldsw.h)
+    uint32_t quad_count = 0, quad_levels = 0;
     bool use_wide = false;           // WideTree kernels (rt_wide.h): the 8-wide tree made from the binary one, for trees read through the caches
     uint32_t wide_count = 0, wide_levels = 0;
     bool device_build = false;       // the tree was built by rt_lbvh.hip
@@ -118,7 +120,7 @@ namespace {
 // SceneDev's pointers from the scene's own buffers (after upload, and after a replica's peer copies)
 void bind_scene_pointers(rt_scene* s) {
     SceneDev& sd = s->dev;
-    sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>(); sd.ldsw_image = s->ldsw_image.as<uint4>();
+    sd.nodes = s->nodes.as<Node>(); sd.list = s->list_nodes.as<Node>(); sd.lds_image = s->lds_image.as<uint4>(); sd.ldsw_image = s->ldsw_image.as<uint4>(); sd.quad_image = s->quad_image.as<uint4>();
     sd.wide_nodes = s->wide_nodes.as<uint4>(); sd.wide_leaves = s->wide_leaves.as<char>();
     sd.obj_code = s->obj_code.as<uint32_t>(); sd.obj_material = s->obj_material.as<uint32_t>();
     sd.obj_shade = s->obj_shade.bytes ? s->obj_shade.as<float4>() : nullptr;
@@ -247,7 +249,8 @@ namespace {
 // W of them (largest surface area first), its children sit in the slots of their quadrant / octant, and the inner children of one node
 // get consecutive indices (breadth first).  Returns false when the tree does not fit the format (more nodes than a stack entry can name).
 struct LdswBuild { std::vector<unsigned char> nodes; uint32_t n_nodes = 0, levels = 0, axis_a = 0, axis_b = 2; };
-bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
+bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out, bool big) {
+    const size_t max_nodes = big ? ((size_t)1 << 28) / LDSW_NODE_UNITS : LDSW_MAX_NODES_LDS;
     constexpr int W = LDSW;
     struct Kid { float mn[3], mx[3]; int code; };
     auto kid = [&](int node, int side) { Kid k; const rtbvh::HostNode& h = bin[node]; for (int a = 0; a < 3; a++) { k.mn[a] = h.q[2 * a + side]; k.mx[a] = h.q[6 + 2 * a + side]; } k.code = side ? h.childB : h.childA; return k; };
@@ -297,7 +300,7 @@ bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
     struct Todo { int bin_node; uint32_t level; };
     std::vector<Todo> todo{{0, 1}};           // todo[i] becomes wide node i
     for (size_t i = 0; i < todo.size(); i++) {
-        if (todo.size() > LDSW_MAX_NODES) return false;
+        if (todo.size() > max_nodes) return false;
         std::vector<Kid> kids;
         {   // the node's own two children, each opened as far as the cost table says: W subtrees in all
             const Kid a = kid(todo[i].bin_node, 0), b = kid(todo[i].bin_node, 1);
@@ -329,7 +332,7 @@ bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
         unsigned char* rec = out.nodes.data() + i * LDSW_NODE_BYTES;
         float* planes = (float*)(rec + LDSW_HEAD_BYTES);
         for (int a = 0; a < 3; a++) for (int sl = 0; sl < W; sl++) { planes[3 * W * a + sl] = 3e38f; planes[3 * W * a + W + sl] = -3e38f; planes[3 * W * a + 2 * W + sl] = 3e38f; }      // an empty slot: no ray meets it
-        uint32_t imask = 0, lmask = 0; unsigned short ids[W] = {};
+        uint32_t imask = 0, lmask = 0; uint32_t ids[W] = {};
         int by_slot[W]; for (int sl = 0; sl < W; sl++) by_slot[sl] = -1;
         for (int k = 0; k < (int)kids.size(); k++) by_slot[slot_of[k]] = k;
         const uint32_t child_base = (uint32_t)todo.size() * LDSW_NODE_UNITS;      // (16-B units)
@@ -338,14 +341,14 @@ bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
             const Kid& k = kids[by_slot[sl]];
             for (int a = 0; a < 3; a++) { planes[3 * W * a + sl] = k.mn[a]; planes[3 * W * a + W + sl] = k.mx[a]; planes[3 * W * a + 2 * W + sl] = k.mn[a]; }
             if (k.code >= 0) { imask |= 1u << sl; todo.push_back({k.code, todo[i].level + 1}); }          // (slots ascending: the k-th inner child is node child_base + k)
-            else { lmask |= 1u << sl; const uint32_t obj = (uint32_t)~k.code; if (obj > 0xFFFFu) return false; ids[sl] = (unsigned short)obj; }
+            else { lmask |= 1u << sl; ids[sl] = (uint32_t)~k.code; }
         }
-        if (child_base + W * LDSW_NODE_UNITS > 65536u) return false;
-        const uint32_t head = child_base | (imask << 16) | (lmask << 24);
-        memcpy(rec, &head, 4); memcpy(rec + 16, ids, sizeof(ids));
+        if (!big && child_base + W * LDSW_NODE_UNITS > 65536u) return false;
+        const uint32_t head[2] = {child_base, imask | (lmask << 8)};
+        memcpy(rec, head, 8); memcpy(rec + 16, ids, sizeof(ids));
         out.levels = std::max(out.levels, todo[i].level);
     }
-    if (todo.size() > LDSW_MAX_NODES) return false;
+    if (todo.size() > max_nodes) return false;
     out.n_nodes = (uint32_t)todo.size();
     {   // every leaf of the binary tree hangs in exactly one slot, every node but the root is exactly one node's child, and every child's
         // box lies inside what the node's slot says: a tree that fails this is not used
@@ -356,28 +359,28 @@ bool build_ldsw(const std::vector<rtbvh::HostNode>& bin, LdswBuild& out) {
         std::vector<int> parents(out.n_nodes, 0);
         for (uint32_t i = 0; i < out.n_nodes; i++) {
             const unsigned char* rec = out.nodes.data() + (size_t)i * LDSW_NODE_BYTES;
-            uint32_t head; memcpy(&head, rec, 4);
-            const uint32_t imask = (head >> 16) & 0xFFu, lmask = head >> 24;
+            uint32_t head[2]; memcpy(head, rec, 8);
+            const uint32_t imask = head[1] & 0xFFu, lmask = (head[1] >> 8) & 0xFFu;
             ok = ok && !(imask & lmask);
             uint32_t rank = 0;
             for (int sl = 0; sl < W; sl++) {
-                if ((lmask >> sl) & 1u) { unsigned short id; memcpy(&id, rec + 16 + 2 * sl, 2); if (id < seen.size()) seen[id]++; else ok = false; wide_leaves++; }
-                if ((imask >> sl) & 1u) { const uint32_t child = ((head & 0xFFFFu) / LDSW_NODE_UNITS) + rank++; if (child < out.n_nodes) parents[child]++; else ok = false; inner_kids++; }
+                if ((lmask >> sl) & 1u) { uint32_t id; memcpy(&id, rec + 16 + 4 * sl, 4); if (id < seen.size()) seen[id]++; else ok = false; wide_leaves++; }
+                if ((imask >> sl) & 1u) { const uint32_t child = (head[0] / LDSW_NODE_UNITS) + rank++; if (child < out.n_nodes) parents[child]++; else ok = false; inner_kids++; }
             }
         }
         // an inner child's record must be the subtree its slot's box was made for: the union of the child's own slots is that box
         for (uint32_t i = 0; i < out.n_nodes; i++) {
             const unsigned char* rec = out.nodes.data() + (size_t)i * LDSW_NODE_BYTES;
-            uint32_t head; memcpy(&head, rec, 4);
+            uint32_t head[2]; memcpy(head, rec, 8);
             const float* pl = (const float*)(rec + LDSW_HEAD_BYTES);
             uint32_t rank = 0;
-            for (int sl = 0; sl < W; sl++) if ((head >> (16 + sl)) & 1u) {
-                const uint32_t child = ((head & 0xFFFFu) / LDSW_NODE_UNITS) + rank++;
+            for (int sl = 0; sl < W; sl++) if ((head[1] >> sl) & 1u) {
+                const uint32_t child = (head[0] / LDSW_NODE_UNITS) + rank++;
                 if (child >= out.n_nodes) { ok = false; continue; }
                 const unsigned char* crec = out.nodes.data() + (size_t)child * LDSW_NODE_BYTES;
-                uint32_t chead; memcpy(&chead, crec, 4);
+                uint32_t chead[2]; memcpy(chead, crec, 8);
                 const float* cpl = (const float*)(crec + LDSW_HEAD_BYTES);
-                const uint32_t used = ((chead >> 16) | (chead >> 24)) & 0xFFu;
+                const uint32_t used = (chead[1] | (chead[1] >> 8)) & 0xFFu;
                 for (int a = 0; a < 3; a++) {
                     float lo = INFINITY, hi = -INFINITY;
                     for (int cs = 0; cs < W; cs++) if ((used >> cs) & 1u) { lo = std::min(lo, cpl[3 * W * a + cs]); hi = std::max(hi, cpl[3 * W * a + W + cs]); }
@@ -754,7 +757,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             const char* ew = getenv("RT_HIP_LDS_WIDE");
             const bool want_w = ew ? (ew[0] == '1' || ew[0] == '2') : RT_LDSW_DEFAULT != 0;
             LdswBuild wb;
-            if (want_w && ks->ldsw.closest && !getenv("RT_HIP_SHADOW_RAYS") && !getenv("RT_HIP_PERSISTENT") && !getenv("RT_HIP_PERSISTENT_SHADOW") && build_ldsw(bvh.nodes, wb)) {
+            if (want_w && ks->ldsw.closest && !getenv("RT_HIP_SHADOW_RAYS") && !getenv("RT_HIP_PERSISTENT") && !getenv("RT_HIP_PERSISTENT_SHADOW") && build_ldsw(bvh.nodes, wb, false)) {
                 const size_t node_bytes = wb.nodes.size(), any_bytes = node_bytes + no * 16, all_bytes = (any_bytes + no * LDSW_BOX_BYTES + 15) & ~(size_t)15;
                 const size_t need_c = all_bytes + (size_t)(wb.levels + 1) * LDSW_BLOCK_CLOSEST * sizeof(LdswEntry), need_a = any_bytes + (size_t)(wb.levels + 1) * LDS_BLOCK_SHADOW * sizeof(LdswEntry);
                 if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: %d-wide LDS tree: %u nodes, %u levels, %zu B for closest-hit kernels, %zu B for any-hit kernels\n", LDSW, wb.n_nodes, wb.levels, need_c, need_a);
@@ -768,7 +771,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
                         for (int a = 0; a < 3; a++) { wbx[6 * i + a] = d->objects[i].aabb_min[a]; wbx[6 * i + 3 + a] = d->objects[i].aabb_max[a]; }
                     }
                     if ((rc = upload(s->ldsw_image, wimg))) return rc;
-                    sd.ldsw_image = s->ldsw_image.as<uint4>(); sd.ldsw_node_bytes = (uint32_t)node_bytes; sd.ldsw_any_bytes = (uint32_t)any_bytes; sd.ldsw_all_bytes = (uint32_t)all_bytes;
+                    sd.ldsw_image = s->ldsw_image.as<uint4>(); sd.quad_image = s->quad_image.as<uint4>(); sd.ldsw_node_bytes = (uint32_t)node_bytes; sd.ldsw_any_bytes = (uint32_t)any_bytes; sd.ldsw_all_bytes = (uint32_t)all_bytes;
                     sd.ldsw_axis_a = wb.axis_a; sd.ldsw_axis_b = wb.axis_b;
                     s->use_ldsw = true; s->use_ldsw_closest = ew && ew[0] == '2'; s->ldsw_count = wb.n_nodes; s->ldsw_levels = wb.levels;
                 }
@@ -799,6 +802,36 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             s->use_wide = true;
             s->stack_depth = std::max<uint32_t>(s->wide_levels + 1, 2);
             if ((size_t)s->stack_depth * BLOCK * sizeof(uint2) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "wide tree of %u levels needs more LDS than one workgroup may use", s->wide_levels);
+        }
+    }
+    // ... and, on request (RT_HIP_QUAD=1), when every leaf is a sphere and the host built the binary tree: the W-wide float form of the same
+    // tree for the ANY-HIT kernels (QuadTree, rt_ldsw.h: one FMA per plane on full-precision boxes, no byte conversions, no near / far
+    // selects, no mask permutations — under half the vector instructions of a quantised 8-wide visit).  Measured on 100 k spheres + 64
+    // lights: 41 instead of 57 box tests per shadow ray, but 12.5 dependent 176-B fetches instead of 7.4 of 80 B: k_shadow_persistent
+    // 427 -> 455 ms per batch.  The kernel waits for its nodes as much as it computes; not the default.
+    {
+        const char* e = getenv("RT_HIP_QUAD");
+        if (s->use_wide && !device_build && sd.wide_inline == RT_HIT_SPHERE && ks->quad.shadow && e && e[0] == '1') {
+            LdswBuild wb;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (build_ldsw(bvh.nodes, wb, true)) {
+                const size_t no = d->n_objects, node_bytes = wb.nodes.size(), any_bytes = node_bytes + no * 16, all_bytes = (any_bytes + no * LDSW_BOX_BYTES + 15) & ~(size_t)15;
+                std::vector<unsigned char> img(all_bytes, 0);
+                memcpy(img.data(), wb.nodes.data(), node_bytes);
+                float4* wsp = (float4*)(img.data() + node_bytes);
+                float* wbx = (float*)(img.data() + any_bytes);
+                for (size_t i = 0; i < no; i++) {
+                    if (d->objects[i].type == RT_HIT_SPHERE) wsp[i] = spheres[d->objects[i].index];
+                    for (int a = 0; a < 3; a++) { wbx[6 * i + a] = d->objects[i].aabb_min[a]; wbx[6 * i + 3 + a] = d->objects[i].aabb_max[a]; }
+                }
+                if ((rc = upload(s->quad_image, img))) return rc;
+                sd.quad_image = s->quad_image.as<uint4>(); sd.quad_node_bytes = (uint32_t)node_bytes;
+                sd.ldsw_axis_a = wb.axis_a; sd.ldsw_axis_b = wb.axis_b;
+                s->use_quad = true; s->quad_count = wb.n_nodes; s->quad_levels = wb.levels;
+                if ((size_t)(wb.levels + 1) * BLOCK * sizeof(uint2) > 64 * 1024) return fail(RT_ERR_TOO_LARGE, "quad tree of %u levels needs more LDS than one workgroup may use", wb.levels);
+                if (getenv("RT_HIP_TIMING")) fprintf(stderr, "rt_hip: %d-wide float tree for any-hit: %u nodes (%zu MB), %u levels: %.1f ms\n", LDSW, wb.n_nodes, node_bytes >> 20, wb.levels,
+                                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
         }
     }
     // Bounce rays in a tree far larger than the L2s have a heavy-tailed cost (measured: 5 M triangles 790 -> 1014 Msamples/s with
@@ -841,7 +874,7 @@ static int clone_scene(const rt_scene* src, int device, rt_scene** out) {
     (void)scratch_for_device(device);      // (best effort, as in rt_scene_create)
     auto s = std::make_unique<rt_scene>();
     s->device = device; s->ks = src->ks; s->dev = src->dev; s->stack_depth = src->stack_depth; s->bvh_depth = src->bvh_depth;
-    s->use_lds = src->use_lds; s->use_ldsw = src->use_ldsw; s->use_ldsw_closest = src->use_ldsw_closest; s->ldsw_count = src->ldsw_count; s->ldsw_levels = src->ldsw_levels; s->use_wide = src->use_wide; s->wide_count = src->wide_count; s->wide_levels = src->wide_levels; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
+    s->use_quad = src->use_quad; s->quad_count = src->quad_count; s->quad_levels = src->quad_levels; s->use_lds = src->use_lds; s->use_ldsw = src->use_ldsw; s->use_ldsw_closest = src->use_ldsw_closest; s->ldsw_count = src->ldsw_count; s->ldsw_levels = src->ldsw_levels; s->use_wide = src->use_wide; s->wide_count = src->wide_count; s->wide_levels = src->wide_levels; s->device_build = src->device_build; s->persistent_shadow = src->persistent_shadow; s->shadow_rays = src->shadow_rays; s->has_phong = src->has_phong; s->any_light_cutoff = src->any_light_cutoff; s->persistent = src->persistent;
     s->n_objects = src->n_objects; s->n_lights = src->n_lights;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -865,6 +898,7 @@ static inline uint32_t grid_for(const rt_scene* s, uint64_t work, uint32_t block
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
 static inline size_t stack_bytes(const rt_scene* s) { return (size_t)s->stack_depth * BLOCK * (s->use_wide ? sizeof(uint2) : sizeof(int)); }
+static inline size_t any_stack_bytes(const rt_scene* s) { return s->use_quad ? (size_t)(s->quad_levels + 1) * BLOCK * sizeof(uint2) : stack_bytes(s); }      // the any-hit kernels' stack columns
 // dynamic LDS of a kernel that holds the tree: the image and the lanes' stack columns.  closest: the W-wide form also carries the objects' exact boxes
 static inline size_t lds_binary_bytes(const rt_scene* s, int block) { return s->dev.lds_image_bytes + (size_t)s->stack_depth * block * sizeof(unsigned short); }
 static inline size_t lds_tree_bytes(const rt_scene* s, int block, bool closest) {
@@ -926,7 +960,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* k_min, const floa
     HIP_TRY(hipMemcpy(d0, k_min, n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d1, k_max, n * sizeof(float), hipMemcpyHostToDevice));
     if (s->use_lds) hipLaunchKernelGGL(s->use_ldsw ? s->ks->ldsw.trace_any : s->ks->trace_any_lds, dim3(lds_grid(s, n, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), 0, s->dev, dr, d0, d1, n, dout);
-    else hipLaunchKernelGGL(s->use_wide ? s->ks->wide.trace_any : s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
+    else hipLaunchKernelGGL(s->use_quad ? s->ks->quad.trace_any : s->use_wide ? s->ks->wide.trace_any : s->ks->trace_any, dim3(grid_for(s, n, 8)), dim3(BLOCK), any_stack_bytes(s), 0, s->dev, dr, d0, d1, n, dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, dout, n, hipMemcpyDeviceToHost));
     trace_release_large(s);
@@ -1208,9 +1242,10 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
         { Timed t(r, RT_K_SHADE, st); hipLaunchKernelGGL(shade_kernel, dim3(g_light), dim3(BLOCK), rd.obj_shade_lds_bytes, st, s->dev, rd, depth); }
         if (trace_shadows) { Timed t(r, RT_K_SHADOW, st);
           if (ray_lanes && s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_rays_lds_exact : ks->shadow_rays_lds, dim3(lds_grid_for(s, (uint64_t)rd.n_paths * per_request, LDS_BLOCK_RAYS, lds_binary_bytes(s, LDS_BLOCK_RAYS) + 3 * LDS_BLOCK_RAYS * sizeof(float))), dim3(LDS_BLOCK_RAYS), lds_binary_bytes(s, LDS_BLOCK_RAYS), st, s->dev, rd, depth);
-          else if (ray_lanes) hipLaunchKernelGGL(s->use_wide ? (ex ? ks->wide.shadow_rays_exact : ks->wide.shadow_rays) : (ex ? ks->shadow_rays_exact : ks->shadow_rays), dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), lds, st, s->dev, rd, depth);
+          else if (ray_lanes) hipLaunchKernelGGL(s->use_quad ? (ex ? ks->quad.shadow_rays_exact : ks->quad.shadow_rays) : s->use_wide ? (ex ? ks->wide.shadow_rays_exact : ks->wide.shadow_rays) : (ex ? ks->shadow_rays_exact : ks->shadow_rays), dim3(grid_for(s, (uint64_t)rd.n_paths * per_request, 8)), dim3(BLOCK), any_stack_bytes(s), st, s->dev, rd, depth);
           else if (s->use_ldsw) hipLaunchKernelGGL(ex ? ks->ldsw.shadow_exact : ks->ldsw.shadow, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
           else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
+          else if (s->use_quad) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->quad.shadow_persistent_exact : ks->quad.shadow_persistent) : (ex ? ks->quad.shadow_exact : ks->quad.shadow), dim3(g_trace), dim3(BLOCK), any_stack_bytes(s), st, s->dev, rd, depth);
           else if (s->use_wide) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->wide.shadow_persistent_exact : ks->wide.shadow_persistent) : (ex ? ks->wide.shadow_exact : ks->wide.shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }

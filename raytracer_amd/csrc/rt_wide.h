@@ -253,4 +253,10 @@ RT_FN bool any_wide(const SceneDev& sc, const WideTree& tree, const WideRay& wr,
     }
 }
 
+// ---- the names k_shadow_persistent uses for either wide tree (rt_ldsw.h has the LdswTreeT overloads)
+RT_FN WideRay wide_ray_idle(const WideTree&) { Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1); return make_wide_ray(r, mk3(0, 0, 1), 0.0f, 1.0f); }
+template <class C> RT_FN bool wide_next_leaf_any(const SceneDev& sc, const WideTree&, WideCursor& c, const WideRay& wr, const Ray& r, float kMin, float kMax) {
+    return wide_leaf_any<C>(sc, wide_take_leaf(c, wr), r, kMin, kMax);
+}
+
 } // namespace rtd

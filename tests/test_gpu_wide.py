@@ -107,10 +107,16 @@ def test_wide_tree_on_small_scenes_rays_and_pictures(name, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [dict(RT_HIP_PERSISTENT="1", RT_HIP_PERSISTENT_SHADOW="1"), dict(RT_HIP_SHADOW_RAYS="1"), dict(RT_HIP_SHADOW_RAYS="0", RT_HIP_PERSISTENT_SHADOW="0"),
-                                 dict(RT_HIP_WIDE_STRIDE="128"), dict(RT_HIP_VARIANT="generic")], ids=lambda e: "+".join(f"{k[7:]}={v}" for k, v in e.items()))
+                                 dict(RT_HIP_WIDE_STRIDE="128"), dict(RT_HIP_VARIANT="generic"),
+                                 dict(RT_HIP_QUAD="1"), dict(RT_HIP_QUAD="1", RT_HIP_PERSISTENT_SHADOW="1"), dict(RT_HIP_QUAD="1", RT_HIP_SHADOW_RAYS="0", RT_HIP_PERSISTENT_SHADOW="0")], ids=lambda e: "+".join(f"{k[7:]}={v}" for k, v in e.items()))
 def test_every_kernel_that_walks_the_wide_tree(env, monkeypatch):
+    """(RT_HIP_QUAD=1: the any-hit kernels walk the 4-wide float form of the tree instead, rt_ldsw.h QuadTree — an opt-in, measured slower on config 5)"""
     sc = helpers.small_scenes()["MiniManyLights"](); flat = flatten_scene(sc)
     wide, binary = _pair(flat, monkeypatch, **env)
+    if "RT_HIP_QUAD" in env:
+        rs = np.random.default_rng(2); orc = ob.OracleScene(flat)
+        so, sd, kmin, kmax = helpers.shadow_ray_set(sc, flat, orc, 60_000, 4)
+        assert np.array_equal(wide.TraceAny(so, sd, kmin, kmax).astype(bool), orc.trace_any(so, sd, kmin, kmax).astype(bool))
     opt = RenderOptions(RenderWidth=128, RenderHeight=72, Passes=2, MaxBounceDepth=5, LightSampleCountHint=1, Seed=8, ExactOcclusion=True)
     out = []
     for dev in (wide, binary):
