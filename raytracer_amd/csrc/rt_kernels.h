@@ -884,10 +884,9 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
     for (;;) {
         bool fetched = false;
         if (!lane_busy()) {
-            if (flying && again && !occluded) {                                 // ---- unoccluded in the boxes as they are: look again in the grown ones
-                if constexpr (WIDE) { wr = wide_ray_any(sc, tree, r, kMax, rd.any_cap, 1, again); wc = wide_start(wr); }
-                else { box = any_box(sc, r, kMax, rd.any_cap, 1, again); cur = 0; sp = stk_empty(); }
-            } else if (flying) {                                                // ---- account for the finished ray
+            int look = -1;                                                      // the ray enters the tree: 0 = first look, 1 = second (ONE place below sets up the traversal: assigned in two, the ray's box lived in the private segment)
+            if (flying && again && !occluded) look = 1;                         // ---- unoccluded in the boxes as they are: look again in the grown ones
+            else if (flying) {                                                // ---- account for the finished ray
                 flying = false;
                 const rt_light* l = sc.lights + li;
                 bool advance = true;
@@ -957,10 +956,11 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
                     }
                 }
                 again = false;
-                if (!occluded && sc.n_nodes) {
-                    if constexpr (WIDE) { wr = wide_ray_any(sc, tree, r, kMax, rd.any_cap, 0, again); wc = wide_start(wr); }
-                    else { box = any_box(sc, r, kMax, rd.any_cap, 0, again); cur = 0; sp = stk_empty(); }
-                }
+                if (!occluded && sc.n_nodes) look = 0;
+            }
+            if (look >= 0) {
+                if constexpr (WIDE) { wr = wide_ray_any(sc, tree, r, kMax, rd.any_cap, look, again); wc = wide_start(wr); }
+                else { box = any_box(sc, r, kMax, rd.any_cap, look, again); cur = 0; sp = stk_empty(); }
             }
         }
         next += (uint32_t)__popcll(__ballot(fetched));

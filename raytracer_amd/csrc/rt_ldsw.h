@@ -86,23 +86,24 @@ typedef uint32_t LdswEntry;
 // ORDERED: the hit slots of a node are entered front to back (closest hit).  Any-hit rays enter them in slot order: in a tree this small
 // the order saves less than the two mask permutations per visit cost (as for the binary LDS tree, whose any-hit walk is unordered too).
 struct LdswRay { f3 inv, an, af; uint32_t ox, oy, oz, octinv; };
+struct LdswAxis { float in, an, af; uint32_t off; bool neg; };      // (one axis at a time, no local arrays: those ended up in the kernel's private segment)
+RT_FN LdswAxis ldsw_axis(float d, float o, float inv, float pad, float lim) {
+    LdswAxis a;
+    a.neg = __builtin_signbitf(d);
+    const float sp = a.neg ? -pad : pad;
+    a.in = __builtin_fminf(__builtin_fmaxf(inv, -lim), lim);
+    a.an = -(o + sp) * a.in;                         // near plane: the min plane moved by -pad for a ray along +axis, the max plane moved by +pad otherwise
+    a.af = -(o - sp) * a.in;
+    a.off = a.neg ? 4u * LDSW : 0u;
+    return a;
+}
 template <bool ORDERED>
 RT_FN LdswRay make_ldsw_ray(const SceneDev& sc, const Ray& r, f3 inv, float pad, float lim) {
+    const LdswAxis x = ldsw_axis(r.d.x, r.o.x, inv.x, pad, lim), y = ldsw_axis(r.d.y, r.o.y, inv.y, pad, lim), z = ldsw_axis(r.d.z, r.o.z, inv.z, pad, lim);
     LdswRay q;
-    const float dd[3] = {r.d.x, r.d.y, r.d.z}, oo[3] = {r.o.x, r.o.y, r.o.z}, ii[3] = {inv.x, inv.y, inv.z};
-    float in_[3], an_[3], af_[3]; uint32_t off[3], neg = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const bool ng = __builtin_signbitf(dd[i]);
-        const float sp = ng ? -pad : pad;
-        in_[i] = __builtin_fminf(__builtin_fmaxf(ii[i], -lim), lim);
-        an_[i] = -(oo[i] + sp) * in_[i];             // near plane: the min plane moved by -pad for a ray along +axis, the max plane moved by +pad otherwise
-        af_[i] = -(oo[i] - sp) * in_[i];
-        off[i] = ng ? 4u * LDSW : 0u;
-        neg |= ng ? 1u << i : 0u;
-    }
-    q.inv = mk3(in_[0], in_[1], in_[2]); q.an = mk3(an_[0], an_[1], an_[2]); q.af = mk3(af_[0], af_[1], af_[2]);
-    q.ox = off[0]; q.oy = off[1]; q.oz = off[2];
+    q.inv = mk3(x.in, y.in, z.in); q.an = mk3(x.an, y.an, z.an); q.af = mk3(x.af, y.af, z.af);
+    q.ox = x.off; q.oy = y.off; q.oz = z.off;
+    const uint32_t neg = (x.neg ? 1u : 0u) | (y.neg ? 2u : 0u) | (z.neg ? 4u : 0u);
     if (!ORDERED) q.octinv = 0u;
     else if (LDSW == 8) q.octinv = 7u ^ neg;
     else q.octinv = 3u ^ (((neg >> sc.ldsw_axis_a) & 1u) | (((neg >> sc.ldsw_axis_b) & 1u) << 1));

@@ -153,6 +153,9 @@ struct Slot {
     DevBuf f32_pool, counters;
 };
 constexpr int MAX_SLOTS = 4;
+#ifndef RT_TRACE_BLOCKS_PER_CU
+#define RT_TRACE_BLOCKS_PER_CU 8
+#endif
 
 struct rt_render {
     rt_scene* scene = nullptr;
@@ -808,7 +811,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     // tree for the ANY-HIT kernels (QuadTree, rt_ldsw.h: one FMA per plane on full-precision boxes, no byte conversions, no near / far
     // selects, no mask permutations — under half the vector instructions of a quantised 8-wide visit).  Measured on 100 k spheres + 64
     // lights: 41 instead of 57 box tests per shadow ray, but 12.5 dependent 176-B fetches instead of 7.4 of 80 B: k_shadow_persistent
-    // 427 -> 455 ms per batch.  The kernel waits for its nodes as much as it computes; not the default.
+    // 425 -> 445 ms per batch.  Not the default.
     {
         const char* e = getenv("RT_HIP_QUAD");
         if (s->use_wide && !device_build && sd.wide_inline == RT_HIT_SPHERE && ks->quad.shadow && e && e[0] == '1') {
@@ -1108,6 +1111,10 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
     for (int si = 0; si < n_slots; si++) {
         Slot& sl = r->slots[si];
         if (si == 0) sl.stream = r->stream;
+        else if (const char* e = getenv("RT_HIP_SLOT_PRIORITY")) {      // A/B knob: the other batch slots' streams at the highest (1) or lowest (-1) priority
+            int lo = 0, hi = 0; HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, atoi(e) > 0 ? hi : atoi(e) < 0 ? lo : 0));
+        }
         else HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_acc[si], hipEventDisableTiming));
         HIP_TRY(sl.counters.alloc(2 * n_cnt * sizeof(uint32_t)));
@@ -1211,7 +1218,8 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     auto shade_kernel = vis != RT_VIS_NONE ? (validate ? k_shade_vis_validate : k_shade_vis) : validate ? k_shade_validate : ks->shade;
     const bool trace_shadows = s->n_lights && (vis == RT_VIS_NONE || vis == RT_VIS_ESTIMATED_LIGHT);
     HIP_TRY(hipMemsetAsync(rd.qcount, 0, 2 * n_cnt * sizeof(uint32_t), st));
-    const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, 8);
+    static const int trace_blocks_per_cu = [] { const char* e = getenv("RT_HIP_TRACE_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : RT_TRACE_BLOCKS_PER_CU; }();      // (A/B knob)
+    const uint32_t g_light = grid_for(s, rd.n_paths, 8), g_trace = grid_for(s, rd.n_paths, (uint32_t)trace_blocks_per_cu);
     const size_t lds = stack_bytes(s);
     // A request with many rays (64 lights: 64 traversals, each ending at its own time) is where a lane should not wait for its
     // wave: 100 k spheres + 64 lights 766 -> 728 ms per batch; with 2-4 rays per request the refill rounds cost more than they save.

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-x}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-BENCH=${BENCH_CMD:-"python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"}
+BENCH=${BENCH_CMD:-"python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-configs --no-exact --no-strong"}
 PASSES=${2:-"sq1 sq2 tcc1 tcc2 tcp1"}
 run() { case " $PASSES " in *" $1 "*) ;; *) return 0;; esac; name=$1; shift; echo "== pass $name: $*"; timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; return 1; }; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE

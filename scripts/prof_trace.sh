@@ -7,6 +7,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-x}
 OUT=$R/gpurun_out/trace_$TAG
 mkdir -p $OUT
-RT_HIP_SLOTS=${RT_HIP_SLOTS:-1} timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+RT_HIP_SLOTS=${RT_HIP_SLOTS:-1} timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-configs --no-exact --no-strong > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 grep '^{' $OUT/run.log
 cat $OUT/t_kernel_stats.csv
