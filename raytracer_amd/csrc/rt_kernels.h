@@ -300,10 +300,13 @@ __global__ void __launch_bounds__(tree_in_lds(TREE) ? lds_block_closest(TREE) : 
 #ifndef RT_CP_WAVES
 #define RT_CP_WAVES 1
 #endif
+#ifndef RT_CPW_WAVES
+#define RT_CPW_WAVES 1      // waves per SIMD k_closest_persistent is held to when it walks the 8-wide tree
+#endif
 constexpr int REFILL_BELOW = RT_REFILL_BELOW, REFILL_MIN_TAKERS = RT_REFILL_MIN_TAKERS;
 
 template <class C, int TREE>
-__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK, RT_CP_WAVES) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
+__global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_CLOSEST : BLOCK, TREE == TREE_WIDE ? RT_CPW_WAVES : RT_CP_WAVES) k_closest_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr bool LDS = TREE == TREE_LDS, WIDE = TREE == TREE_WIDE;
     constexpr int TB = LDS ? LDS_BLOCK_CLOSEST : BLOCK;
     const auto tree = make_tree<TREE, TB>(sc);
@@ -849,6 +852,11 @@ template <class C> struct ShadowPersistentWideTune { static constexpr int min_wa
 #ifndef RT_SPQ_WAVES
 #define RT_SPQ_WAVES 1
 #endif
+#ifdef RT_SPW_PROF
+constexpr uint32_t SPW_COUNTS = 0;      // (measurement builds: the three counters hold rounds and lanes, see below)
+#else
+constexpr uint32_t SPW_COUNTS = 1;
+#endif
 template <class C, int TREE, bool EXACT = false>
 __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, EXACT ? 1 : TREE == TREE_QUAD ? RT_SPQ_WAVES : TREE == TREE_WIDE ? ShadowPersistentWideTune<C>::min_waves : ShadowPersistentTune<C>::min_waves) k_shadow_persistent(SceneDev sc, RenderDev rd, uint32_t depth) {
     constexpr bool WIDE = TREE == TREE_WIDE || TREE == TREE_QUAD;
@@ -883,6 +891,9 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
     if (per_request == 0) return;                                               // (the host launches no shadow kernel without lights)
     for (;;) {
         bool fetched = false;
+#ifdef RT_SPW_PROF
+        if (WIDE && RT_SPW_PROF == 2) { if (__any(!lane_busy()) && lane_id() == (uint32_t)__builtin_ctzll(__ballot(true))) rays++; if (!lane_busy()) nodes++; }
+#endif
         if (!lane_busy()) {
             int look = -1;                                                      // the ray enters the tree: 0 = first look, 1 = second (ONE place below sets up the traversal: assigned in two, the ray's box lived in the private segment)
             if (flying && again && !occluded) look = 1;                         // ---- unoccluded in the boxes as they are: look again in the grown ones
@@ -940,18 +951,21 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
             if (have && !flying) {                                              // ---- next ray of the request
                 ShadowRay sr = light_shadow_ray<C, EXACT>(sc, sc.lights + li, wp, nrm, key, depth, second ? SLOT_LIGHT_RAW : SLOT_LIGHT, q);
                 r = sr.r; kMin = sr.kMin; kMax = sr.kMax;
-                rays++; flying = true; occluded = false;
+#ifndef RT_SPW_PROF
+                rays++;
+#endif
+                flying = true; occluded = false;
                 if (RT_SKIP_MUTE_RAYS && rd.skip_mute_rays && !phong) {         // a ray whose light cannot change the sum is not traced (see k_shadow): accounted as if occluded, the same bits
                     const col3 unoccluded = light_contribution<EXACT>(sc.lights + li, kMax), t = sum + unoccluded;
                     occluded = t.r == sum.r && t.g == sum.g && t.b == sum.b;
                 }
                 for (uint32_t i = 0; i < sc.n_unbounded && !occluded; i++) {
-                    uint32_t code = sc.obj_code[sc.unbounded[i]]; prims++;
+                    uint32_t code = sc.obj_code[sc.unbounded[i]]; prims += SPW_COUNTS;
                     occluded = fast_object_solid<C>(sc, code >> OBJ_TYPE_SHIFT, code & OBJ_INDEX_MASK, r, kMin, kMax);
                 }
                 if constexpr (RT_HAS_PRIM(C, RT_HIT_MEDIUM)) {
                     for (uint32_t i = 0; i < sc.n_media && !occluded; i++) {
-                        rt_medium md = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; prims++;
+                        rt_medium md = sc.media_rec[sc.obj_code[sc.media[i]] & OBJ_INDEX_MASK]; prims += SPW_COUNTS;
                         occluded = fast_object_solid<C>(sc, md.boundary_type, md.boundary_index, r, kMin, kMax);      // ConstantDensityMedium.cs:77
                     }
                 }
@@ -973,11 +987,25 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
         spins = 0;
         for (;;) {
             if constexpr (WIDE) {
-                while (wide_vote(wc)) if (wide_can_step(wc)) nodes += wide_step(sc, tree, wr, kMin, kMax, wc);
+#ifdef RT_SPW_PROF      // (one-off measurement builds: rounds of the wave against the lanes that use them, in the three counters.  1: step rounds, lane steps, leaf rounds; 2: refill rounds, lanes refilled, lane leaves)
+                while (wide_vote(wc)) {
+                    if (RT_SPW_PROF == 1 && lane_id() == (uint32_t)__builtin_ctzll(__ballot(true))) rays++;
+                    if (wide_can_step(wc)) { const uint32_t nb = wide_step_any(sc, tree, wr, kMin, kMax, wc); nodes += RT_SPW_PROF == 1 ? 1u : 0u * nb; }
+                }
+                if (RT_SPW_PROF == 1 && __any(wide_has_leaf(wc)) && lane_id() == (uint32_t)__builtin_ctzll(__ballot(true))) prims++;
+                if (wide_has_leaf(wc)) {
+                    if (RT_SPW_PROF == 2) prims++;
+                    if (wide_next_leaf_any<C>(sc, tree, wc, wr, r, kMin, kMax)) { occluded = true; wide_stop(wc); }
+                }
+#else
+                while (wide_vote(wc)) if (wide_can_step(wc)) nodes += wide_step_any(sc, tree, wr, kMin, kMax, wc);
+#endif
+#ifndef RT_SPW_PROF
                 if (wide_has_leaf(wc)) {
                     prims++;
                     if (wide_next_leaf_any<C>(sc, tree, wc, wr, r, kMin, kMax)) { occluded = true; wide_stop(wc); }
                 }
+#endif
             } else {
                 while (step_vote(cur, pend)) if (cur >= 0) { nodes += 2; node_step<true>(sc, tree, box, kMin, kMax, cur, pend, sp, unused); }
                 if (pend != TRAV_DONE) {

@@ -251,7 +251,7 @@ RT_FN bool any_wide(const SceneDev& sc, const LdswTreeT<BIG>& tree, const LdswRa
 // ---- the names k_shadow_persistent uses for either wide tree (rt_wide.h has the WideTree overloads)
 template <bool BIG> RT_FN LdswRay wide_ray_idle(const LdswTreeT<BIG>&) { LdswRay q; q.inv = mk3(0, 0, 1); q.an = mk3(0, 0, 0); q.af = mk3(0, 0, 0); q.ox = 0; q.oy = 0; q.oz = 0; q.octinv = 0; return q; }
 RT_FN WideCursor wide_start(const LdswRay& q) { return ldsw_start(q); }
-template <bool BIG> RT_FN uint32_t wide_step(const SceneDev&, const LdswTreeT<BIG>& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) { return ldsw_step<BIG && RT_QUAD_ORDERED>(tree, q, kMin, kMax, c); }
+template <bool BIG> RT_FN uint32_t wide_step_any(const SceneDev&, const LdswTreeT<BIG>& tree, const LdswRay& q, float kMin, float kMax, WideCursor& c) { return ldsw_step<BIG && RT_QUAD_ORDERED>(tree, q, kMin, kMax, c); }
 template <class C, bool BIG> RT_FN bool wide_next_leaf_any(const SceneDev&, const LdswTreeT<BIG>& tree, WideCursor& c, const LdswRay& q, const Ray& r, float kMin, float kMax) {
     float k; return try_sphere(tree.sph[ldsw_take_leaf<BIG && RT_QUAD_ORDERED>(tree, c, q)], r, kMin, kMax, k);
 }

@@ -1254,7 +1254,7 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
           else if (s->use_ldsw) hipLaunchKernelGGL(ex ? ks->ldsw.shadow_exact : ks->ldsw.shadow, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
           else if (s->use_lds) hipLaunchKernelGGL(ex ? ks->shadow_lds_exact : ks->shadow_lds, dim3(lds_grid(s, rd.n_paths, LDS_BLOCK_SHADOW, false)), dim3(LDS_BLOCK_SHADOW), lds_tree_bytes(s, LDS_BLOCK_SHADOW, false), st, s->dev, rd, depth);
           else if (s->use_quad) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->quad.shadow_persistent_exact : ks->quad.shadow_persistent) : (ex ? ks->quad.shadow_exact : ks->quad.shadow), dim3(g_trace), dim3(BLOCK), any_stack_bytes(s), st, s->dev, rd, depth);
-          else if (s->use_wide) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->wide.shadow_persistent_exact : ks->wide.shadow_persistent) : (ex ? ks->wide.shadow_exact : ks->wide.shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth);
+          else if (s->use_wide) hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->wide.shadow_persistent_exact : ks->wide.shadow_persistent) : (ex ? ks->wide.shadow_exact : ks->wide.shadow), dim3(g_trace), dim3(BLOCK), any_stack_bytes(s), st, s->dev, rd, depth);
           else hipLaunchKernelGGL(shadow_persistent ? (ex ? ks->shadow_persistent_exact : ks->shadow_persistent) : (ex ? ks->shadow_exact : ks->shadow), dim3(g_trace), dim3(BLOCK), lds, st, s->dev, rd, depth); }
     }
     // the adds into the image sums happen in batch order whatever slot a batch ran on

@@ -47,12 +47,19 @@ struct WideTree {
 // pad * lim = 1e6 scene sizes / |d| on the far side — beyond any hit — instead of inf - inf or an overflow of q * S (a scene 1e17
 // units across times 1/d = 1e24).
 constexpr float WIDE_INV_LIMIT = ANY_INV_LIMIT;
+// Any-hit rays enter children and test leaves in SLOT order (RT_WIDE_ANY_ORDERED 0): whether a ray is occluded does not depend on the
+// order, most shadow rays are not occluded and have to see everything their box pad lets through anyway, and the two mask
+// permutations of an ordered visit are 30 of its 230 vector instructions.  Closest-hit rays go front to back.
+#ifndef RT_WIDE_ANY_ORDERED
+#define RT_WIDE_ANY_ORDERED 0
+#endif
+template <bool ORDERED = true>
 RT_FN WideRay make_wide_ray(const Ray& r, f3 inv, float pad, float lim) {
     WideRay w; w.o = r.o;
     w.inv = mk3(__builtin_fminf(__builtin_fmaxf(inv.x, -lim), lim), __builtin_fminf(__builtin_fmaxf(inv.y, -lim), lim), __builtin_fminf(__builtin_fmaxf(inv.z, -lim), lim));
     w.pt = mk3(pad * fabsf(w.inv.x), pad * fabsf(w.inv.y), pad * fabsf(w.inv.z));
     w.neg = (__builtin_signbitf(inv.x) ? 1u : 0u) | (__builtin_signbitf(inv.y) ? 2u : 0u) | (__builtin_signbitf(inv.z) ? 4u : 0u);
-    w.octinv = 7u ^ w.neg;
+    w.octinv = ORDERED ? 7u ^ w.neg : 0u;
     return w;
 }
 // Closest hit.  The reference's leaf test computes fl(fl(plane - o) * inv): at most 2 * 2^-24 |plane - o| away from the real number.
@@ -78,9 +85,9 @@ RT_FN WideRay wide_ray_any(const SceneDev& sc, const WideTree&, const Ray& r, fl
     again = mode == 0 && round > (sc.any_again * rm);
     const f3 inv = mk3(rcp_fast(r.d.x), rcp_fast(r.d.y), rcp_fast(r.d.z));
     const float lim = WIDE_INV_LIMIT * rcp_fast(len);
-    if (again) return make_wide_ray(r, inv, 0.0f, lim);
+    if (again) return make_wide_ray<RT_WIDE_ANY_ORDERED>(r, inv, 0.0f, lim);
     // (+ the FMA form's own rounding against far_side, as for closest hit: a visit places a plane within 2.4e-7 far_side)
-    return make_wide_ray(r, inv, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z))) + (4e-7f * far_side)), lim);
+    return make_wide_ray<RT_WIDE_ANY_ORDERED>(r, inv, sc.any_pad_scale * (round + (1e-6f * reach) + 1e-5f + (2.4e-7f * __builtin_fmaxf(__builtin_fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z))) + (4e-7f * far_side)), lim);
 }
 
 RT_FN uint32_t lane_id_() { return threadIdx.x & 63u; }
@@ -94,6 +101,20 @@ RT_FN uint32_t xor_permute8(uint32_t m, uint32_t x) {
     return m;
 }
 
+// the same for two masks side by side (bits 0-7 and 8-15)
+#ifndef RT_WIDE_ADDC
+#define RT_WIDE_ADDC 1
+#endif
+#ifndef RT_WIDE_JOINT_PERMUTE
+#define RT_WIDE_JOINT_PERMUTE 0
+#endif
+RT_FN uint32_t xor_permute8x2(uint32_t m, uint32_t x) {
+    if (x & 4u) m = ((m & 0x0F0Fu) << 4) | ((m >> 4) & 0x0F0Fu);
+    if (x & 2u) m = ((m & 0x3333u) << 2) | ((m >> 2) & 0x3333u);
+    if (x & 1u) m = ((m & 0x5555u) << 1) | ((m >> 1) & 0x5555u);
+    return m;
+}
+
 // One node: which of its (up to) eight child boxes the ray's [kMin, kMax] meets.  `hits` in slot order; the caller splits it by imask / lmask.
 struct WideVisit { uint32_t hits, imask, lmask, child_base, leaf_base; };
 RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node, float kMin, float kMax) {
@@ -103,7 +124,7 @@ RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node,
     const float sx = __uint_as_float((h0.w & 0xFFu) << 23), sy = __uint_as_float(((h0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((h0.w >> 16) & 0xFFu) << 23);
     const float Sx = sx * wr.inv.x, Sy = sy * wr.inv.y, Sz = sz * wr.inv.z;
     const float Ax = (__uint_as_float(h0.x) - wr.o.x) * wr.inv.x, Ay = (__uint_as_float(h0.y) - wr.o.y) * wr.inv.y, Az = (__uint_as_float(h0.z) - wr.o.z) * wr.inv.z;
-    const v2f Bx = {Ax - wr.pt.x, Ax + wr.pt.x}, By = {Ay - wr.pt.y, Ay + wr.pt.y}, Bz = {Az - wr.pt.z, Az + wr.pt.z};      // (near, far) addends
+    const v2f Bx = (v2f){Ax, Ax} + (v2f){-wr.pt.x, wr.pt.x}, By = (v2f){Ay, Ay} + (v2f){-wr.pt.y, wr.pt.y}, Bz = (v2f){Az, Az} + (v2f){-wr.pt.z, wr.pt.z};      // (near, far) addends: one v_pk_add_f32 each (neg_lo)
     const v2f SSx = {Sx, Sx}, SSy = {Sy, Sy}, SSz = {Sz, Sz};
     const bool gx = wr.neg & 1u, gy = wr.neg & 2u, gz = wr.neg & 4u;
     // near / far plane bytes: the lo planes are the near ones for a ray along +axis, the hi planes otherwise
@@ -112,13 +133,19 @@ RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node,
     const uint32_t nz[2] = {gz ? rz.z : rz.x, gz ? rz.w : rz.y}, fz[2] = {gz ? rz.x : rz.z, gz ? rz.y : rz.w};
     uint32_t hits = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
+    for (int c = 7; c >= 0; c--) {                   // slot 7 first: `hits` is shifted up as the slots below it arrive
         const int w = c >> 2, b = c & 3;
         const v2f qx = {ubyte_f(nx[w], b), ubyte_f(fx[w], b)}, qy = {ubyte_f(ny[w], b), ubyte_f(fy[w], b)}, qz = {ubyte_f(nz[w], b), ubyte_f(fz[w], b)};
         const v2f tx = __builtin_elementwise_fma(qx, SSx, Bx), ty = __builtin_elementwise_fma(qy, SSy, By), tz = __builtin_elementwise_fma(qz, SSz, Bz);
         const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tx.x, kMin), ty.x), tz.x);      // a NaN distance (0 * inf cannot happen with the clamp; inf - inf can) never replaces a bound
         const float ex = __builtin_fminf(__builtin_fminf(__builtin_fminf(tx.y, kMax), ty.y), tz.y);
-        hits |= !(ex < en) ? (1u << c) : 0u;                                                              // closed interval: a box met on a face or an edge is entered
+        // closed interval: a box met on a face or an edge is entered.  hits = 2 * hits + !(ex < en): compare into vcc, add with carry
+        // (the compiler's own form is compare, select a constant, shift / or: 2.5 instead of 2 instructions per box)
+#if RT_WIDE_ADDC
+        asm("v_cmp_nlt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %3, %3, vcc" : "=v"(hits) : "v"(ex), "v"(en), "v"(hits) : "vcc");
+#else
+        hits = (hits + hits) + (!(ex < en) ? 1u : 0u);
+#endif
     }
     WideVisit v;
     v.imask = h0.w >> 24; v.lmask = h1.z & 0xFFu; v.child_base = h1.x; v.leaf_base = h1.y;
@@ -132,7 +159,7 @@ RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node,
 // entering a child while siblings remain pushes the group, an exhausted group pops one — at most one entry per level.
 struct WideCursor { uint32_t gbase, gbits, pbase, pbits; int sp; };
 RT_FN WideCursor wide_idle() { WideCursor c; c.gbase = 0; c.gbits = 0; c.pbase = 0; c.pbits = 0; c.sp = 0; return c; }
-RT_FN WideCursor wide_start(const WideRay& wr) {      // the root as a one-child group: node 0 in slot 0
+RT_FN WideCursor wide_start(const WideRay& wr) {      // the root as a one-child group: node 0 in slot 0 (octinv = 0 for a ray that takes its children in slot order)
     WideCursor c = wide_idle(); c.gbits = (1u << wr.octinv) | (1u << 8); return c;
 }
 RT_FN bool wide_can_step(const WideCursor& c) { return (c.gbits & 0xFFu) != 0u && (c.pbits & 0xFFu) == 0u; }
@@ -141,26 +168,39 @@ RT_FN bool wide_busy(const WideCursor& c) { return ((c.gbits | c.pbits) & 0xFFu)
 RT_FN void wide_stop(WideCursor& c) { c.gbits = 0; c.pbits = 0; c.sp = 0; }
 
 // Enter the nearest child still in G and test its children.  Returns the number of boxes tested.
+template <bool ORDERED = true>
 RT_FN uint32_t wide_step(const SceneDev& sc, const WideTree& tree, const WideRay& wr, float kMin, float kMax, WideCursor& c) {
     const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.gbits & 0xFFu);
-    const uint32_t slot = pi ^ wr.octinv, imask = (c.gbits >> 8) & 0xFFu;
+    const uint32_t slot = ORDERED ? pi ^ wr.octinv : pi, imask = (c.gbits >> 8) & 0xFFu;
     const uint32_t node = c.gbase + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
     const uint32_t rest = c.gbits & ~(1u << pi);                 // the siblings still to enter
     const WideVisit v = wide_visit(sc, wr, node, kMin, kMax);
-    c.pbase = v.leaf_base; c.pbits = xor_permute8(v.hits & v.lmask, wr.octinv) | (v.lmask << 8);
-    const uint32_t inner = v.hits & v.imask;
+    uint32_t ph = v.hits & v.lmask, inner = v.hits & v.imask, gh = inner;
+    if (ORDERED) {
+#if RT_WIDE_JOINT_PERMUTE
+        const uint32_t both = xor_permute8x2(ph | (inner << 8), wr.octinv);      // both masks in one pass
+        ph = both & 0xFFu; gh = both >> 8;
+#else
+        ph = xor_permute8(ph, wr.octinv);
+#endif
+    }
+    c.pbase = v.leaf_base; c.pbits = ph | (v.lmask << 8);
     if (inner) {                                                  // descend: the siblings wait in the lane's column
         if (rest & 0xFFu) { tree.push(c.sp, make_uint2(c.gbase, rest)); c.sp++; }
-        c.gbase = v.child_base; c.gbits = xor_permute8(inner, wr.octinv) | (v.imask << 8);
+#if !RT_WIDE_JOINT_PERMUTE
+        if (ORDERED) gh = xor_permute8(inner, wr.octinv);
+#endif
+        c.gbase = v.child_base; c.gbits = gh | (v.imask << 8);
     } else if (rest & 0xFFu) c.gbits = rest;                      // nothing below: on with the siblings
     else if (c.sp) { c.sp--; const uint2 e = tree.pop(c.sp); c.gbase = e.x; c.gbits = e.y; }
     else c.gbits = 0;
     return (uint32_t)__builtin_popcount(v.imask | v.lmask);
 }
 // the next leaf of P (the nearest slot first): its record's index
+template <bool ORDERED = true>
 RT_FN uint32_t wide_take_leaf(WideCursor& c, const WideRay& wr) {
     const uint32_t pi = 31u - (uint32_t)__builtin_clz(c.pbits & 0xFFu);
-    const uint32_t slot = pi ^ wr.octinv, lmask = (c.pbits >> 8) & 0xFFu;
+    const uint32_t slot = ORDERED ? pi ^ wr.octinv : pi, lmask = (c.pbits >> 8) & 0xFFu;
     c.pbits &= ~(1u << pi);
     return c.pbase + (uint32_t)__builtin_popcount(lmask & ((1u << slot) - 1u));
 }
@@ -247,16 +287,16 @@ template <class C>
 RT_FN bool any_wide(const SceneDev& sc, const WideTree& tree, const WideRay& wr, const Ray& r, float kMin, float kMax, TravCount& cnt) {
     WideCursor c = wide_start(wr);
     for (;;) {
-        while (wide_vote(c)) if (wide_can_step(c)) cnt.nodes += wide_step(sc, tree, wr, kMin, kMax, c);
-        if (wide_has_leaf(c)) { cnt.prims++; if (wide_leaf_any<C>(sc, wide_take_leaf(c, wr), r, kMin, kMax)) return true; }
+        while (wide_vote(c)) if (wide_can_step(c)) cnt.nodes += wide_step<RT_WIDE_ANY_ORDERED>(sc, tree, wr, kMin, kMax, c);
+        if (wide_has_leaf(c)) { cnt.prims++; if (wide_leaf_any<C>(sc, wide_take_leaf<RT_WIDE_ANY_ORDERED>(c, wr), r, kMin, kMax)) return true; }
         if (!wide_busy(c)) return false;
     }
 }
-
 // ---- the names k_shadow_persistent uses for either wide tree (rt_ldsw.h has the LdswTreeT overloads)
-RT_FN WideRay wide_ray_idle(const WideTree&) { Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1); return make_wide_ray(r, mk3(0, 0, 1), 0.0f, 1.0f); }
+RT_FN WideRay wide_ray_idle(const WideTree&) { Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1); return make_wide_ray<RT_WIDE_ANY_ORDERED>(r, mk3(0, 0, 1), 0.0f, 1.0f); }
+RT_FN uint32_t wide_step_any(const SceneDev& sc, const WideTree& tree, const WideRay& wr, float kMin, float kMax, WideCursor& c) { return wide_step<RT_WIDE_ANY_ORDERED>(sc, tree, wr, kMin, kMax, c); }
 template <class C> RT_FN bool wide_next_leaf_any(const SceneDev& sc, const WideTree&, WideCursor& c, const WideRay& wr, const Ray& r, float kMin, float kMax) {
-    return wide_leaf_any<C>(sc, wide_take_leaf(c, wr), r, kMin, kMax);
+    return wide_leaf_any<C>(sc, wide_take_leaf<RT_WIDE_ANY_ORDERED>(c, wr), r, kMin, kMax);
 }
 
 } // namespace rtd
