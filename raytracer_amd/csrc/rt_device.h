@@ -800,8 +800,8 @@ RT_FN AnyBox any_box(const SceneDev& sc, const Ray& r, float kMax, float cap, in
 struct WideTree;
 struct WideRay {              // what a node visit of the wide tree needs of the ray
     f3 o, inv, pt;            // origin, 1/d clamped, pad * |1/d| per axis
-    uint32_t neg;             // bit a: the ray runs against axis a
-    uint32_t octinv;          // 7 - octant
+    uint32_t ax, ay, az;      // byte offset in a node record of the axis's (near planes, far planes) pair: 8 further along when the ray runs against the axis
+    uint32_t octinv;          // 7 - octant (0 for a ray that takes a node's children in slot order)
 };
 template <class C> RT_FN void closest_wide(const SceneDev& sc, const WideTree& tree, const Ray& r, float kMin, Closest& best, TravCount& cnt);
 template <class C> RT_FN bool any_wide(const SceneDev& sc, const WideTree& tree, const WideRay& wr, const Ray& r, float kMin, float kMax, TravCount& cnt);

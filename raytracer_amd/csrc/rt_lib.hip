@@ -787,12 +787,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         const char* e = getenv("RT_HIP_WIDE");
         const bool want = e ? e[0] == '1' : n_nodes >= 1024;
         sd.wide_inline = RT_NO_HIT;
-        if (want && !s->use_lds && !sd.n_list_pairs && boxes.size() >= 2 && n_nodes == boxes.size() - 1) {
+        if (want && !s->use_lds && !sd.n_list_pairs && boxes.size() >= 2 && n_nodes == boxes.size() - 1 && n_nodes < WIDE_MAX_NODES) {      // (more nodes than a visit's 24-bit multiply addresses: the binary tree serves)
             uint32_t one_type = d->objects[box_obj[0]].type;
             for (uint32_t obj : box_obj) if (d->objects[obj].type != one_type) { one_type = RT_NO_HIT; break; }
             const uint32_t inline_type = (one_type == RT_HIT_SPHERE || one_type == RT_HIT_TRIANGLE || one_type == RT_HIT_QUAD) ? one_type : (uint32_t)RT_NO_HIT;
             uint32_t stride = WIDE_NODE_BYTES;
-            if (const char* st = getenv("RT_HIP_WIDE_STRIDE")) stride = std::max<uint32_t>(WIDE_NODE_BYTES, ((uint32_t)atoi(st) + 15u) & ~15u);
+            if (const char* st = getenv("RT_HIP_WIDE_STRIDE")) stride = std::max<uint32_t>(WIDE_NODE_BYTES, ((uint32_t)atoi(st) + 7u) & ~7u);
             void *wn = nullptr, *wl = nullptr; size_t wnb = 0, wlb = 0; uint32_t lstride = 0;
             std::string err;
             const auto t0 = std::chrono::steady_clock::now();
@@ -1131,6 +1131,13 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.qcount = sl.counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
         rd.stats = r->stats.as<unsigned long long>();
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
+        {   // slots of a pass in 8 x 8 tiles (rt_kernels.h: slot_pixel) where the image has whole tiles; RT_HIP_TILES=0: row order (A/B, tests)
+            const char* e = getenv("RT_HIP_TILES");
+            const uint32_t tpr = o->width / 8u, bands = o->height / 8u;
+            const bool tiles = !(e && e[0] == '0') && (o->width % 8u) == 0 && tpr >= 2 && bands > 0 && (uint64_t)tpr * bands * tpr < (1ull << 32);
+            rd.tiled_slots = tiles ? bands * 8u * o->width : 0u; rd.tiles_per_row = tiles ? tpr : 1u;
+            rd.tile_magic = tiles ? (uint32_t)(((1ull << 32) + tpr - 1) / tpr) : 0u;
+        }
         rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;
         rd.max_depth = o->max_bounce_depth; rd.light_samples = o->light_sample_count_hint;
         rd.compact_requests = (!s->has_phong && o->debug_visualisation == RT_VIS_NONE && !getenv("RT_HIP_FULL_REQUESTS")) ? 1u : 0u;

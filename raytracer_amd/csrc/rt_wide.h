@@ -10,17 +10,20 @@
 // of a quarter the size (5 M triangles: 320 MB -> 88 MB, inside the 256 MB Infinity Cache).  The leaf's exact box sits in front
 // of a copy of its primitive in a leaf-ordered table: one fetch gives the reference's box test and the intersector's operands.
 //
-// Node record (80 B, five 16-B loads; WideNode in rt_wide.hip writes it):
-//   q0 = (org.x, org.y, org.z, ex | ey << 8 | ez << 16 | imask << 24)   frame origin = min corner; e = biased exponent of the axis scale 2^(e-127)
-//   q1 = (child_base, leaf_base, lmask, -)                              first inner child / first leaf record; imask, lmask: which slots hold an inner node / a leaf
-//   q2 = (lo.x[0..3], lo.x[4..7], hi.x[0..3], hi.x[4..7])               one byte per slot: plane = org + q * 2^(e-127), rounded outward
-//   q3 = the same for y, q4 for z                                       (an empty slot: lo = 255, hi = 0 and in neither mask)
+// Node record (104 B; WideNode in rt_wide.hip writes it):
+//   +0   org.x, org.y, org.z, ex << 23 | imask      frame origin = min corner; e = biased exponent of the axis scale 2^(e-127), in a float's exponent field
+//   +16  child_base, leaf_base, ey << 23 | lmask, ez << 23      first inner child / first leaf record; imask, lmask: which slots hold an inner node / a leaf
+//   +32  lo.x[0..7] hi.x[0..7] lo.x[0..7]           one byte per slot: plane = org + q * 2^(e-127), rounded outward (an empty slot: lo = 255, hi = 0 and in neither mask)
+//   +56  the same for y, +80 for z
+// The low planes stand twice so that the ray's direction picks its (near planes, far planes) pair by ADDRESS: a ray along +axis reads
+// 16 B at +0 of the block (lo, hi), a ray against it at +8 (hi, lo) — the trick of the LDS image (rt_kernels.h: LdsTree); the 80-B
+// record of round 3's first form held each plane once and a visit chose with twelve v_cndmask.
 // The k-th inner child (slots in ascending order) is node child_base + k, the k-th leaf is record leaf_base + k.
 // Slots are assigned by octant (Ylitie, Karras, Laine 2017): a child on the (-x, -y, -z) side of the node sits in slot 0, on
 // (+x, +y, +z) in slot 7, so visiting the hit slots by descending (slot XOR (7 - ray octant)) is front to back with no sorting.
 //
 // Box arithmetic of a visit (both kinds of ray): t = q * (2^e * inv) + ((org - o) * inv -+ pad * |inv|), one cvt and one FMA per
-// plane.  `pad` makes it conservative against the reference's own rounding of the leaf test (closest hit: 1e-6 of the farthest
+// plane, no selects.  `pad` makes it conservative against the reference's own rounding of the leaf test (closest hit: 1e-6 of the farthest
 // distance from the ray origin to anything in the scene — the FMA form and the reference's (plane - o) * inv differ by at most
 // 3.6e-7 of that, see wide_ray_closest) or is the any-hit pad of rt_device.h (any_box); inv is clamped (make_wide_ray) so that an
 // axis-parallel ray gives +-huge, not inf - inf.
@@ -29,7 +32,9 @@
 
 namespace rtd {
 
-constexpr uint32_t WIDE_NODE_BYTES = 80;
+constexpr uint32_t WIDE_NODE_BYTES = 104;
+constexpr uint32_t WIDE_AXIS_BYTES = 24, WIDE_HEAD_BYTES = 32;
+constexpr uint32_t WIDE_MAX_NODES = 1u << 24;      // a visit forms node * stride with v_mul_u32_u24 and addresses the record by a 32-bit offset
 constexpr uint32_t WIDE_LEAF_BOX_BYTES = 32;     // (min.xyz, object) (max.xyz, object code): then the primitive's record when the tree holds one type (sc.wide_inline)
 
 struct WideTree {
@@ -58,8 +63,9 @@ RT_FN WideRay make_wide_ray(const Ray& r, f3 inv, float pad, float lim) {
     WideRay w; w.o = r.o;
     w.inv = mk3(__builtin_fminf(__builtin_fmaxf(inv.x, -lim), lim), __builtin_fminf(__builtin_fmaxf(inv.y, -lim), lim), __builtin_fminf(__builtin_fmaxf(inv.z, -lim), lim));
     w.pt = mk3(pad * fabsf(w.inv.x), pad * fabsf(w.inv.y), pad * fabsf(w.inv.z));
-    w.neg = (__builtin_signbitf(inv.x) ? 1u : 0u) | (__builtin_signbitf(inv.y) ? 2u : 0u) | (__builtin_signbitf(inv.z) ? 4u : 0u);
-    w.octinv = ORDERED ? 7u ^ w.neg : 0u;
+    const uint32_t gx = __builtin_signbitf(inv.x) ? 1u : 0u, gy = __builtin_signbitf(inv.y) ? 1u : 0u, gz = __builtin_signbitf(inv.z) ? 1u : 0u;
+    w.ax = WIDE_HEAD_BYTES + 8u * gx; w.ay = WIDE_HEAD_BYTES + WIDE_AXIS_BYTES + 8u * gy; w.az = WIDE_HEAD_BYTES + 2u * WIDE_AXIS_BYTES + 8u * gz;
+    w.octinv = ORDERED ? 7u ^ (gx | (gy << 1) | (gz << 2)) : 0u;
     return w;
 }
 // Closest hit.  The reference's leaf test computes fl(fl(plane - o) * inv): at most 2 * 2^-24 |plane - o| away from the real number.
@@ -115,22 +121,21 @@ RT_FN uint32_t xor_permute8x2(uint32_t m, uint32_t x) {
     return m;
 }
 
+struct __attribute__((aligned(8))) WideQuad { uint32_t x, y, z, w; };      // 16 B of a node record (records and their axis blocks are 8-B aligned: one global_load_dwordx4 all the same)
 // One node: which of its (up to) eight child boxes the ray's [kMin, kMax] meets.  `hits` in slot order; the caller splits it by imask / lmask.
 struct WideVisit { uint32_t hits, imask, lmask, child_base, leaf_base; };
 RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node, float kMin, float kMax) {
-    const uint4* np = (const uint4*)((const char*)sc.wide_nodes + (size_t)node * sc.wide_stride);
-    const uint4 h0 = np[0], h1 = np[1], rx = np[2], ry = np[3], rz = np[4];
+    const char* base = (const char*)sc.wide_nodes;
+    const uint32_t off = __umul24(node, sc.wide_stride);      // (rt_lib.hip: fewer than 2^24 nodes, the array below 4 GB)
+    const WideQuad h0 = *(const WideQuad*)(base + off), h1 = *(const WideQuad*)(base + (off + 16u));
+    const WideQuad rx = *(const WideQuad*)(base + (off + wr.ax)), ry = *(const WideQuad*)(base + (off + wr.ay)), rz = *(const WideQuad*)(base + (off + wr.az));      // (near[0..3], near[4..7], far[0..3], far[4..7])
     __builtin_amdgcn_sched_barrier(0);           // the five loads in flight before the first wait
-    const float sx = __uint_as_float((h0.w & 0xFFu) << 23), sy = __uint_as_float(((h0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((h0.w >> 16) & 0xFFu) << 23);
+    const float sx = __uint_as_float(h0.w & 0x7F800000u), sy = __uint_as_float(h1.z & 0x7F800000u), sz = __uint_as_float(h1.w);
     const float Sx = sx * wr.inv.x, Sy = sy * wr.inv.y, Sz = sz * wr.inv.z;
     const float Ax = (__uint_as_float(h0.x) - wr.o.x) * wr.inv.x, Ay = (__uint_as_float(h0.y) - wr.o.y) * wr.inv.y, Az = (__uint_as_float(h0.z) - wr.o.z) * wr.inv.z;
     const v2f Bx = (v2f){Ax, Ax} + (v2f){-wr.pt.x, wr.pt.x}, By = (v2f){Ay, Ay} + (v2f){-wr.pt.y, wr.pt.y}, Bz = (v2f){Az, Az} + (v2f){-wr.pt.z, wr.pt.z};      // (near, far) addends: one v_pk_add_f32 each (neg_lo)
     const v2f SSx = {Sx, Sx}, SSy = {Sy, Sy}, SSz = {Sz, Sz};
-    const bool gx = wr.neg & 1u, gy = wr.neg & 2u, gz = wr.neg & 4u;
-    // near / far plane bytes: the lo planes are the near ones for a ray along +axis, the hi planes otherwise
-    const uint32_t nx[2] = {gx ? rx.z : rx.x, gx ? rx.w : rx.y}, fx[2] = {gx ? rx.x : rx.z, gx ? rx.y : rx.w};
-    const uint32_t ny[2] = {gy ? ry.z : ry.x, gy ? ry.w : ry.y}, fy[2] = {gy ? ry.x : ry.z, gy ? ry.y : ry.w};
-    const uint32_t nz[2] = {gz ? rz.z : rz.x, gz ? rz.w : rz.y}, fz[2] = {gz ? rz.x : rz.z, gz ? rz.y : rz.w};
+    const uint32_t nx[2] = {rx.x, rx.y}, fx[2] = {rx.z, rx.w}, ny[2] = {ry.x, ry.y}, fy[2] = {ry.z, ry.w}, nz[2] = {rz.x, rz.y}, fz[2] = {rz.z, rz.w};
     uint32_t hits = 0;
 #pragma unroll
     for (int c = 7; c >= 0; c--) {                   // slot 7 first: `hits` is shifted up as the slots below it arrive
@@ -148,7 +153,7 @@ RT_FN WideVisit wide_visit(const SceneDev& sc, const WideRay& wr, uint32_t node,
 #endif
     }
     WideVisit v;
-    v.imask = h0.w >> 24; v.lmask = h1.z & 0xFFu; v.child_base = h1.x; v.leaf_base = h1.y;
+    v.imask = h0.w & 0xFFu; v.lmask = h1.z & 0xFFu; v.child_base = h1.x; v.leaf_base = h1.y;
     v.hits = hits & (v.imask | v.lmask);
     return v;
 }

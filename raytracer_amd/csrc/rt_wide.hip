@@ -175,11 +175,14 @@ __global__ void __launch_bounds__(TB) k_write(const Node* nodes, const uint32_t*
     uint32_t imask = 0, lmask = 0;
     for (int s = 0; s < 8; s++) if (child_in[s] >= 0) { if (c[child_in[s]].ref >= 0) imask |= 1u << s; else lmask |= 1u << s; }
     // the node record
-    uint4* np = (uint4*)(wide_nodes + (size_t)(first_node + i) * node_stride);
+    uint32_t* np = (uint32_t*)(wide_nodes + (size_t)(first_node + i) * node_stride);      // (rt_wide.h has the layout; records are 8-B aligned)
     auto pack4 = [](const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
-    np[0] = make_uint4(__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(lo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24));
-    np[1] = make_uint4(child_base, leaf_base, lmask, 0u);
-    for (int a = 0; a < 3; a++) np[2 + a] = make_uint4(pack4(qlo[a]), pack4(qlo[a] + 4), pack4(qhi[a]), pack4(qhi[a] + 4));
+    np[0] = __float_as_uint(lo[0]); np[1] = __float_as_uint(lo[1]); np[2] = __float_as_uint(lo[2]); np[3] = (eb[0] << 23) | imask;
+    np[4] = child_base; np[5] = leaf_base; np[6] = (eb[1] << 23) | lmask; np[7] = eb[2] << 23;
+    for (int a = 0; a < 3; a++) {
+        uint32_t* ap = np + 8 + 6 * a;
+        ap[0] = pack4(qlo[a]); ap[1] = pack4(qlo[a] + 4); ap[2] = pack4(qhi[a]); ap[3] = pack4(qhi[a] + 4); ap[4] = ap[0]; ap[5] = ap[1];
+    }
     // children in slot order: inner ones become the next level's items, leaves their records
     uint32_t ki = 0, kl = 0;
     for (int s = 0; s < 8; s++) {

@@ -67,8 +67,8 @@ def snap(job):
 
 
 def wide_model(info, b_prim):
-    """Bytes per box test in the 8-wide tree (rt_wide.h): a node visit reads one 80-B record and tests every child slot in use, so an inner
-    box test costs 80 B x nodes / child slots in use (the tree's mean; a binary tree of n inner nodes has n + 1 leaves, and every wide node
+    """Bytes per box test in the 8-wide tree (rt_wide.h): a node visit reads 80 B of one 104-B record (header, and per axis the 16 B its
+    direction picks) and tests every child slot in use, so an inner box test costs 80 B x nodes / child slots in use (the tree's mean; a binary tree of n inner nodes has n + 1 leaves, and every wide node
     but the root is somebody's child); a leaf's exact box is the 32 B in front of its primitive record."""
     if not info.get("wide_nodes"):
         return None
@@ -129,7 +129,7 @@ def run_config(c, short=False, traffic=None, exact=False):
     tr = traffic.get(c, {}).get("kernels", {})
     tnames = [k for k in tr if k.startswith("k_" + dominant)]
     # a tree far larger than the caches (the node array alone beyond 64 MB, binary or wide): its fetches are what can bound the kernel
-    tree_bytes = info["wide_nodes"] * 80 if info["wide_nodes"] else info["n_nodes"] * 64
+    tree_bytes = info["wide_nodes"] * 104 if info["wide_nodes"] else info["n_nodes"] * 64
     hbm_bound = tree_bytes > (64 << 20)
     if tnames:
         # the half of the coalesced path-state reads that FETCH_SIZE leaves out (k_closest: 2 float4 per ray; k_shadow: 3 float4 per request + its 16-B target)

@@ -331,6 +331,26 @@ def test_ragged_batches_tiny_images_and_zero_passes(pairs):
     job.Dispose()
 
 
+@pytest.mark.parametrize("scene,w,h", [("Demo", 200, 101), ("Testing", 64, 8), ("Testing", 24, 40), ("CornellBox", 100, 60)])
+def test_tile_order_of_the_paths_changes_no_bit(pairs, monkeypatch, scene, w, h):
+    """A pass's paths are numbered tile by tile (8 x 8 pixels, rt_kernels.h: slot_pixel) wherever the image has whole tiles, in row order
+    elsewhere (200 x 101: 12 bands of tiles + 5 rows; 100 x 60: a width that is no multiple of 8, so no tiles at all).  The order is
+    nobody's business but the scheduler's: sums, sample counts and every counter equal those of row order (RT_HIP_TILES=0)."""
+    sc, flat, dev, orc = pairs(scene)
+    def run():
+        job = rt.RenderJob(sc, RenderOptions(RenderWidth=w, RenderHeight=h, Passes=5, MaxBounceDepth=8, Seed=4242, PassesPerBatch=2), device_scene=dev)
+        job.RenderPasses(0, 5, 1)
+        a, n = job.ReadAccum(); st = job.UpdateStats(); job.Dispose()
+        return a, n, st
+    a, n, st = run()
+    monkeypatch.setenv("RT_HIP_TILES", "0")
+    b, nb, stb = run()
+    assert n == nb == 5 and np.array_equal(a, b)
+    for k in ("RayCount", "ShadowRays", "PixelsRendered", "MaterialScatterCount", "SkyRays", "BounceLimitExceeded"):
+        if hasattr(st, k): assert getattr(st, k) == getattr(stb, k), k
+    assert st.RayDepthCounts == stb.RayDepthCounts
+
+
 def test_more_materials_than_the_path_state_can_name_are_refused():
     """Material ids travel in 16 bits beside the path id: 65 535 distinct materials are refused, not truncated."""
     from raytracer_amd import impl
