@@ -47,8 +47,9 @@ struct RenderDev {
     unsigned long long* stats;// [ST_COUNT]
     uint32_t width, height, n_pixels;
     uint32_t tiled_slots, tiles_per_row, tile_magic;      // slot_pixel: the first tiled_slots slots of a pass are 8 x 8 tiles (0: row order throughout); tile_magic = ceil(2^32 / tiles_per_row)
+    uint32_t pass_shift, group_paths;                     // path_pass_pixel: the batch's passes go in groups of 2^pass_shift, group_paths = n_pixels << pass_shift
     uint32_t n_paths;         // pixels * passes in this batch
-    uint64_t first_pass; uint32_t pass_stride;    // pass of path p = first_pass + (p / n_pixels) * pass_stride
+    uint64_t first_pass; uint32_t pass_stride;    // pass of path p = first_pass + (its pass in the batch, path_pass_pixel) * pass_stride
     uint64_t seed;
     float k_min, k_max;
     uint32_t max_depth, light_samples;
@@ -158,24 +159,35 @@ RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compac
     }
 }
 
-// Path number <-> pixel.  Path id of a batch = pass-in-batch * n_pixels + slot.  Slot s of a pass is pixel s in row order — or, for
-// the first rd.tiled_slots slots, the pixels of 8 x 8 tiles, one tile after the other (whole bands of 8 rows of an image whose width
-// is a multiple of 8; rt_lib.hip, RT_HIP_TILES=0 for row order): the 64 paths of a wave start on a square of pixels instead of a
-// 64 x 1 strip, and the compacted queues of the later bounces inherit that neighbourhood.  Measured: Night Spheres 3680 -> 3752
-// Msamples/s (k_closest 51.5 -> 49.6, k_shadow 68.3 -> 66.9 ms per step), 5 M triangles 1030 -> 1078 (short runs).  Nothing else
-// knows about the order: the RNG is keyed by the PIXEL and k_accumulate adds by pixel, so the image is the same bit for bit.
+// Path number <-> (pass, pixel).  A batch's passes go in groups of g = 2^pass_shift (the largest power of two that divides their
+// number, at most 16: rt_lib.hip); inside a group the paths are numbered slot by slot and, for one slot, pass by pass:
+//     id = group * (n_pixels * g) + slot * g + pass-in-group
+// and slot s of the image is not pixel s either: for the first rd.tiled_slots slots the slots walk 8 x 8-pixel tiles, one tile after
+// the other (whole bands of 8 rows of an image whose width is a multiple of 8; rt_lib.hip).  With 16 passes in a group a wave's 64
+// camera rays are 16 samples each of a 2 x 2 block of pixels, neighbouring waves neighbouring blocks of a tile, where the
+// reference's loop nest (pass by pass, row by row) would make them a 64 x 1 strip of one pass: the rays of a wave stay together in
+// the tree, end on the same object, ask for the same light from the same place — and since survivors are compacted in order the
+// queues of every later bounce inherit the neighbourhood.  Nothing else knows about the order: the RNG is keyed by (pixel, pass) and
+// k_accumulate adds a pixel's passes in pass order, so the image is the same bit for bit (RT_HIP_TILES=0: row order,
+// RT_HIP_PASS_GROUP=0: pass-major numbering; A/B runs and tests).  Measured, both together: Night Spheres 3680 -> 3800 Msamples/s,
+// 5 M triangles 1030 -> 1142 (short runs), Cornell and 100 k spheres + 64 lights unchanged.
 RT_FN uint32_t slot_pixel(const RenderDev& rd, uint32_t slot) {
     if (slot >= rd.tiled_slots) return slot;
     const uint32_t tile = slot >> 6, ty = __umulhi(tile, rd.tile_magic), tx = tile - ty * rd.tiles_per_row;      // (exact: the host checks n_tiles * tiles_per_row < 2^32)
     return ((ty << 3) | ((slot >> 3) & 7u)) * rd.width + ((tx << 3) | (slot & 7u));
 }
+RT_FN void path_pass_pixel(const RenderDev& rd, uint32_t id, uint32_t& pass, uint32_t& pix) {
+    const uint32_t k = id / rd.group_paths, l = id - k * rd.group_paths;
+    pass = (k << rd.pass_shift) | (l & ((1u << rd.pass_shift) - 1u));
+    pix = slot_pixel(rd, l >> rd.pass_shift);
+}
 RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
-    uint32_t b = id / rd.n_pixels, pix = slot_pixel(rd, id - b * rd.n_pixels);
+    uint32_t b, pix; path_pass_pixel(rd, id, b, pix);
     return make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
 }
 
 // RenderPixelWithVisualisations (None branch), RenderJob.cs:135-151 + Camera.GetRay: the camera ray of path `id` of the batch
-// (pass id / n_pixels of the batch, pixel id % n_pixels).  A function of the path's number alone, so depth 0 needs no k_raygen
+// (pass and pixel: path_pass_pixel).  A function of the path's number alone, so depth 0 needs no k_raygen
 // pass that writes 64 B of state per path for the first closest-hit launch to read back: with rd.implicit_primary that launch
 // makes the rays itself.  What the first k_shade launch needs of them it either makes again (rd.implicit_primary == 1) or reads
 // (== 2: the closest-hit launch leaves the 32 B of origin and direction; throughput 1, radiance 0 and the path number are
@@ -187,7 +199,7 @@ RT_FN RngKey path_key(const RenderDev& rd, uint32_t id) {
 #define RT_PRIMARY_STORE 1
 #endif
 RT_FN Ray primary_ray(const SceneDev& sc, const RenderDev& rd, uint32_t id) {
-    uint32_t b = id / rd.n_pixels, pix = slot_pixel(rd, id - b * rd.n_pixels);
+    uint32_t b, pix; path_pass_pixel(rd, id, b, pix);
     uint32_t x = pix % rd.width, y = pix / rd.width;                                   // Decompress2DIndex, MathUtils.cs:38-43
     RngKey key = make_key(rd.seed, pix, rd.first_pass + (uint64_t)b * rd.pass_stride);
     float4 u = rng_draw(key, 0, SLOT_CAMERA, 0);
@@ -658,7 +670,8 @@ __global__ void __launch_bounds__(BLOCK, VIS || VALIDATE ? 1 : SHADE_MIN_WAVES) 
                 }
                 scat++;                                                                   // RenderJob.cs:439
                 if constexpr (VIS) {
-                    const uint32_t pix = slot_pixel(rd, id % rd.n_pixels), px = pix % rd.width, py = pix / rd.width;
+                    uint32_t pass_, pix; path_pass_pixel(rd, id, pass_, pix);
+                    const uint32_t px = pix % rd.width, py = pix / rd.width;
                     float z = h.k - rd.k_min;
                     switch (rd.vis) {
                         case RT_VIS_NORMALS: { f3 n = (h.n + splat(1.0f)) / 2.0f; L = mkc(n.x, n.y, n.z); } break;
@@ -1036,19 +1049,34 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
 }
 
 #ifdef RT_KERNELS_COMMON
-// UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — passes of the batch are added in pass order.
+// UpdateBuffers' accumulation, RenderJob.cs:626-647: flip y, sum += sample — the passes of the batch are added in pass order.
+// The g = 2^pass_shift passes of a slot are neighbours in rd.out (path_pass_pixel), so a workgroup reads BLOCK consecutive paths at a
+// time — the g passes of BLOCK / g slots, one coalesced 4-KB read — through LDS, and the first BLOCK / g threads add their slot's g
+// values in order; the running sums stay in those threads' registers from one group of passes to the next.
 __global__ void __launch_bounds__(BLOCK) k_accumulate(RenderDev rd, float* accum, uint32_t n_passes) {
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < rd.n_pixels; slot += gridDim.x * BLOCK) {
-        const uint32_t pix = slot_pixel(rd, slot);
-        uint32_t x = pix % rd.width, y = pix / rd.width;
-        uint32_t yy = rd.height - y - 1;
-        float* dst = accum + 3 * ((size_t)x + (size_t)yy * rd.width);
-        float r = dst[0], g = dst[1], b = dst[2];
-        for (uint32_t p = 0; p < n_passes; p++) {
-            float4 v = rd.out[(size_t)p * rd.n_pixels + slot];
-            r += v.x; g += v.y; b += v.z;
+    __shared__ float4 stage[BLOCK];
+    const uint32_t g = 1u << rd.pass_shift, slots_per_chunk = BLOCK >> rd.pass_shift, n_groups = n_passes >> rd.pass_shift;
+    const uint32_t n_chunks = (rd.n_pixels + slots_per_chunk - 1) / slots_per_chunk;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t slot = chunk * slots_per_chunk + threadIdx.x;
+        const bool mine = threadIdx.x < slots_per_chunk && slot < rd.n_pixels;
+        float* dst = nullptr; float r = 0, gr = 0, b = 0;
+        if (mine) {
+            const uint32_t pix = slot_pixel(rd, slot), x = pix % rd.width, y = pix / rd.width, yy = rd.height - y - 1;
+            dst = accum + 3 * ((size_t)x + (size_t)yy * rd.width);
+            r = dst[0]; gr = dst[1]; b = dst[2];
         }
-        dst[0] = r; dst[1] = g; dst[2] = b;
+        const uint32_t first = chunk * BLOCK;                                   // = chunk's first slot * g: where its paths start inside a group
+        for (uint32_t k = 0; k < n_groups; k++) {
+            if (first + threadIdx.x < rd.group_paths) stage[threadIdx.x] = rd.out[(size_t)k * rd.group_paths + first + threadIdx.x];
+            __syncthreads();
+            if (mine) {
+#pragma unroll 8
+                for (uint32_t p = 0; p < g; p++) { const float4 v = stage[(threadIdx.x << rd.pass_shift) + p]; r += v.x; gr += v.y; b += v.z; }
+            }
+            __syncthreads();
+        }
+        if (mine) { dst[0] = r; dst[1] = gr; dst[2] = b; }
     }
 }
 

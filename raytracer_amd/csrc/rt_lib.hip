@@ -1213,6 +1213,14 @@ static int enqueue_batch(rt_render* r, int si, uint64_t first, uint32_t np, uint
     Slot& sl = r->slots[si];
     RenderDev rd = sl.rd;
     rd.n_paths = rd.n_pixels * np; rd.first_pass = first; rd.pass_stride = stride;
+    {   // the batch's passes in groups of the largest power of two that divides their number, at most 16 (rt_kernels.h: path_pass_pixel); RT_HIP_PASS_GROUP=n: at most 2^n, n <= 6.
+        // Measured: 5 M triangles (16 passes per batch) 1068 / 1110 / 1115 / 1142 Msamples/s in short runs with groups of 1 / 4 / 8 / 16; Night Spheres
+        // (64 per batch) 3794 / 3804 / 3820 / 3802, and 3682 with groups of 64, where k_accumulate's four adding threads per workgroup cost more than the walks gain
+        const char* e = getenv("RT_HIP_PASS_GROUP"); const int cap = e ? std::min(6, std::max(0, atoi(e))) : 4;
+        uint32_t sh = 0;
+        while ((int)sh < cap && !((np >> sh) & 1u)) sh++;
+        rd.pass_shift = sh; rd.group_paths = rd.n_pixels << sh;
+    }
     hipStream_t st = sl.stream;
     const KernelSet* ks = s->ks;
     const uint32_t n_cnt = r->opts.max_bounce_depth + 2;
