@@ -46,7 +46,7 @@ struct RenderDev {
     uint32_t* sqcount;        // [max_depth + 2] shadow requests per bounce
     unsigned long long* stats;// [ST_COUNT]
     uint32_t width, height, n_pixels;
-    uint32_t tiled_slots, tiles_per_row, tile_magic;      // slot_pixel: the first tiled_slots slots of a pass are 8 x 8 tiles (0: row order throughout); tile_magic = ceil(2^32 / tiles_per_row)
+    uint32_t tiled_slots, tiles_per_row, tile_magic, tile_shift;      // slot_pixel: the first tiled_slots slots of a pass go tile by tile (0: row order throughout), tiles of 2^tile_shift pixels a side; tile_magic = ceil(2^32 / tiles_per_row)
     uint32_t pass_shift, group_paths;                     // path_pass_pixel: the batch's passes go in groups of 2^pass_shift, group_paths = n_pixels << pass_shift
     uint32_t n_paths;         // pixels * passes in this batch
     uint64_t first_pass; uint32_t pass_stride;    // pass of path p = first_pass + (its pass in the batch, path_pass_pixel) * pass_stride
@@ -162,8 +162,8 @@ RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compac
 // Path number <-> (pass, pixel).  A batch's passes go in groups of g = 2^pass_shift (the largest power of two that divides their
 // number, at most 16: rt_lib.hip); inside a group the paths are numbered slot by slot and, for one slot, pass by pass:
 //     id = group * (n_pixels * g) + slot * g + pass-in-group
-// and slot s of the image is not pixel s either: for the first rd.tiled_slots slots the slots walk 8 x 8-pixel tiles, one tile after
-// the other (whole bands of 8 rows of an image whose width is a multiple of 8; rt_lib.hip).  With 16 passes in a group a wave's 64
+// and slot s of the image is not pixel s either: for the first rd.tiled_slots slots the slots walk the image tile by tile, in Z order
+// inside a tile (32 x 32 pixels where the width is a multiple of 32, else 8 x 8, rows that fill no tile in row order; rt_lib.hip).  With 16 passes in a group a wave's 64
 // camera rays are 16 samples each of a 2 x 2 block of pixels, neighbouring waves neighbouring blocks of a tile, where the
 // reference's loop nest (pass by pass, row by row) would make them a 64 x 1 strip of one pass: the rays of a wave stay together in
 // the tree, end on the same object, ask for the same light from the same place — and since survivors are compacted in order the
@@ -171,10 +171,15 @@ RT_FN void req_tail(const RenderDev& rd, uint32_t depth, uint32_t p, bool compac
 // k_accumulate adds a pixel's passes in pass order, so the image is the same bit for bit (RT_HIP_TILES=0: row order,
 // RT_HIP_PASS_GROUP=0: pass-major numbering; A/B runs and tests).  Measured, both together: Night Spheres 3680 -> 3800 Msamples/s,
 // 5 M triangles 1030 -> 1142 (short runs), Cornell and 100 k spheres + 64 lights unchanged.
+RT_FN uint32_t even_bits(uint32_t v) {      // bits 0, 2, 4, 6, 8 of v side by side
+    v &= 0x555u; v = (v | (v >> 1)) & 0x333u;
+    return ((v | (v >> 2)) & 0x0Fu) | ((v >> 4) & 0x10u);
+}
 RT_FN uint32_t slot_pixel(const RenderDev& rd, uint32_t slot) {
     if (slot >= rd.tiled_slots) return slot;
-    const uint32_t tile = slot >> 6, ty = __umulhi(tile, rd.tile_magic), tx = tile - ty * rd.tiles_per_row;      // (exact: the host checks n_tiles * tiles_per_row < 2^32)
-    return ((ty << 3) | ((slot >> 3) & 7u)) * rd.width + ((tx << 3) | (slot & 7u));
+    const uint32_t sh = rd.tile_shift, in = slot & ((1u << (2u * sh)) - 1u), tile = slot >> (2u * sh);
+    const uint32_t ty = __umulhi(tile, rd.tile_magic), tx = tile - ty * rd.tiles_per_row;      // (exact: the host checks n_tiles * tiles_per_row < 2^32)
+    return ((ty << sh) | even_bits(in >> 1)) * rd.width + ((tx << sh) | even_bits(in));       // Z order inside the tile: 4, 16, 64, ... consecutive slots are squares
 }
 RT_FN void path_pass_pixel(const RenderDev& rd, uint32_t id, uint32_t& pass, uint32_t& pix) {
     const uint32_t k = id / rd.group_paths, l = id - k * rd.group_paths;

@@ -1057,6 +1057,9 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         // other batch to overlap with).  Measured, Night Spheres 1080p, one job end to end (scripts/strong_batching.py): 64 passes as
         // 1 x 64 3298, as 2 x 32 3431 Msamples/s; 32 passes 3084 -> 3163; 16 passes 2796 -> 2894 (steady state, 256 passes: 3590).
         if (o->max_passes_per_call >= 16 && o->max_passes_per_call < 2 * ppb) ppb = (o->max_passes_per_call + 1) / 2;
+        // ... and a batch's passes are numbered in groups of the largest power of two that divides their number (enqueue_batch), so a
+        // multiple of 8 where there is room for one (groups of 8 give most of what groups of 16 do), of 4 or 2 below
+        if (ppb >= 8) ppb &= ~7u; else if (ppb >= 4) ppb = 4; else if (ppb >= 2) ppb = 2;
     }
     if (n_pixels * ppb > (1ull << 30)) return fail(RT_ERR_TOO_LARGE, "passes_per_batch * pixels exceeds 2^30 paths");
     // concurrent batches: default 2 (RT_HIP_SLOTS overrides, test/tuning knob)
@@ -1131,11 +1134,15 @@ static int create_single(rt_scene* s, const rt_render_opts* o, rt_render** out) 
         rd.qcount = sl.counters.as<uint32_t>(); rd.sqcount = rd.qcount + n_cnt;
         rd.stats = r->stats.as<unsigned long long>();
         rd.width = o->width; rd.height = o->height; rd.n_pixels = (uint32_t)n_pixels;
-        {   // slots of a pass in 8 x 8 tiles (rt_kernels.h: slot_pixel) where the image has whole tiles; RT_HIP_TILES=0: row order (A/B, tests)
+        {   // slots of a pass tile by tile (rt_kernels.h: slot_pixel): 32 x 32 pixels where the width is a multiple of 32, else 8 x 8 where it is one
+            // of 8, rows that fill no tile in row order; RT_HIP_TILES=0 / 8 / 32: row order / 8 x 8 at most / as said (A/B, tests)
             const char* e = getenv("RT_HIP_TILES");
-            const uint32_t tpr = o->width / 8u, bands = o->height / 8u;
-            const bool tiles = !(e && e[0] == '0') && (o->width % 8u) == 0 && tpr >= 2 && bands > 0 && (uint64_t)tpr * bands * tpr < (1ull << 32);
-            rd.tiled_slots = tiles ? bands * 8u * o->width : 0u; rd.tiles_per_row = tiles ? tpr : 1u;
+            const uint32_t want = e ? (uint32_t)atoi(e) : 32u;
+            uint32_t sh = 0;
+            for (uint32_t t : {5u, 3u}) if (!sh && want >= (1u << t) && (o->width % (1u << t)) == 0 && o->width >= (2u << t) && o->height >= (1u << t)) sh = t;
+            const uint32_t tpr = sh ? o->width >> sh : 1u, bands = sh ? o->height >> sh : 0u;
+            const bool tiles = sh && (uint64_t)tpr * bands * tpr < (1ull << 32);
+            rd.tiled_slots = tiles ? (bands << sh) * o->width : 0u; rd.tiles_per_row = tiles ? tpr : 1u; rd.tile_shift = tiles ? sh : 0u;
             rd.tile_magic = tiles ? (uint32_t)(((1ull << 32) + tpr - 1) / tpr) : 0u;
         }
         rd.seed = o->seed; rd.k_min = o->k_min; rd.k_max = o->k_max;

@@ -332,13 +332,15 @@ def test_ragged_batches_tiny_images_and_zero_passes(pairs):
 
 
 @pytest.mark.parametrize("scene,w,h,passes,ppb", [("Demo", 200, 101, 5, 2), ("Testing", 64, 8, 16, 16), ("Testing", 24, 40, 12, 12), ("CornellBox", 100, 60, 8, 8),
-                                                  ("Testing", 72, 48, 64, 64)])
+                                                  ("Testing", 72, 48, 64, 64), ("Testing", 96, 70, 8, 8)])
 def test_the_numbering_of_the_paths_changes_no_bit(pairs, monkeypatch, scene, w, h, passes, ppb):
     """Inside a batch the paths are numbered slot by slot, a slot's passes side by side in groups of the largest power of two that divides
-    the batch's passes, and the slots walk 8 x 8-pixel tiles wherever the image has whole tiles (rt_kernels.h: path_pass_pixel; 200 x 101:
-    12 bands of tiles + 5 rows in row order; 100 x 60: a width that is no multiple of 8, so no tiles at all; 5 passes in batches of 2: groups
-    of 2, 2 and 1; 12: groups of 4; 64: groups of 16, and of 64 with RT_HIP_PASS_GROUP=6 — one pixel's samples are a wave).  The order is nobody's business but the scheduler's: sums, sample
-    counts and every counter equal those of the reference's loop nest, pass by pass and row by row (RT_HIP_PASS_GROUP=0, RT_HIP_TILES=0)."""
+    the batch's passes, and the slots walk the image tile by tile in Z order — tiles of 32 x 32 pixels where the width is a multiple of 32,
+    of 8 x 8 where it is one of 8 — with the rows that fill no tile in row order (rt_kernels.h: path_pass_pixel; 96 x 70: two bands of
+    32 x 32 tiles + 6 rows; 200 x 101: 12 bands of 8 x 8 tiles + 5 rows; 100 x 60: no tiles at all; 5 passes in batches of 2: groups of 2, 2
+    and 1; 12: groups of 4; 64: groups of 16, and of 64 with RT_HIP_PASS_GROUP=6 — one pixel's samples are a wave).  The order is nobody's
+    business but the scheduler's: sums, sample counts and every counter equal those of the reference's loop nest, pass by pass and row
+    by row (RT_HIP_PASS_GROUP=0, RT_HIP_TILES=0)."""
     sc, flat, dev, orc = pairs(scene)
     def run():
         job = rt.RenderJob(sc, RenderOptions(RenderWidth=w, RenderHeight=h, Passes=passes, MaxBounceDepth=8, Seed=4242, PassesPerBatch=ppb), device_scene=dev)
@@ -354,8 +356,11 @@ def test_the_numbering_of_the_paths_changes_no_bit(pairs, monkeypatch, scene, w,
     d, nd, std_ = run()
     monkeypatch.setenv("RT_HIP_PASS_GROUP", "6")
     e, ne, ste = run()
-    assert n == nb == nc == nd == ne == passes and np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
-    for other in (stb, stc, std_, ste):
+    monkeypatch.setenv("RT_HIP_TILES", "8")
+    f, nf, stf = run()
+    assert n == nb == nc == nd == ne == nf == passes
+    for other in (b, c, d, e, f): assert np.array_equal(a, other)
+    for other in (stb, stc, std_, ste, stf):
         for k in ("RayCount", "ShadowRays", "PixelsRendered", "MaterialScatterCount", "SkyRays", "BounceLimitExceeded"):
             assert getattr(st, k) == getattr(other, k), k
         assert st.RayDepthCounts == other.RayDepthCounts
