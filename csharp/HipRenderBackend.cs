@@ -336,8 +336,12 @@ internal sealed unsafe class HipRenderBackend : IRenderBackend
 				pass += n;
 				Publish(job, hRender, rgb, normalsWrong, uvInvalid);               // the GUIs poll Image / RenderStats at 30 Hz without locks (RenderBufferPanel.cs:53-79)
 				// next call: as many passes as fit TargetSecondsPerCall at the rate just seen, a multiple of the device count, at most the library's batch
+				// (per device a multiple of 8 once there is room for 8, of 4 or 2 below: the library traces a batch's passes in groups of the largest
+				//  power of two that divides their number, DESIGN.md §4)
 				double want = n * TargetSecondsPerCall / seconds;
-				perCall = (uint)Math.Clamp(Math.Floor(want / nDev), 1.0, (double)MaxPassesPerCall) * nDev;
+				uint each = (uint)Math.Clamp(Math.Floor(want / nDev), 1.0, (double)MaxPassesPerCall);
+				each = each >= 8 ? each & ~7u : each >= 4 ? 4u : each >= 2 ? 2u : 1u;
+				perCall = each * nDev;
 			}
 			job.Stopwatch.Stop();
 		}

@@ -305,7 +305,7 @@ typedef struct rt_render_opts {
     uint32_t light_sample_count_hint;/* LightSampleCountHint (2), >= 1 */
     uint32_t debug_visualisation;    /* rt_debug_vis */
     uint64_t seed;                   /* key of the counter RNG that replaces Random.Shared (RandUtils.cs:17) */
-    uint32_t passes_per_batch;       /* passes traced per wavefront batch; 0 = library default (see max_passes_per_call) */
+    uint32_t passes_per_batch;       /* passes traced per wavefront batch; 0 = library default (see max_passes_per_call; a multiple of 8 where there is room: a batch's passes are traced in groups) */
     int32_t  device;                 /* HIP device ordinal, -1 = the scene's device (ignored when n_devices > 1) */
     void*    stream;                 /* hipStream_t to enqueue on, NULL = a stream owned by the library (must be NULL when n_devices > 1) */
     float*   accum_device;           /* optional caller-owned DEVICE buffer of width*height*3 floats (zeroed by the

@@ -6,8 +6,8 @@
 // (Core/Acceleration/SingleObjectBvhNode.cs:10-16: the object is asked only if its own AxisAlignedBoundingBox.Hit passes); inner
 // boxes merely have to be conservative (BinaryBvhNode.cs:13-37 returns what its children return), and any-hit has no box test at
 // all in the reference (BinaryBvhNode.cs:41).  So inner nodes hold EIGHT children whose boxes are 8-bit offsets in the node's own
-// frame, rounded outward: one 80-B record per visit instead of three 64-B ones, a third of the dependent fetches, and a node array
-// of a quarter the size (5 M triangles: 320 MB -> 88 MB, inside the 256 MB Infinity Cache).  The leaf's exact box sits in front
+// frame, rounded outward: one 104-B record per visit instead of three 64-B ones, a third of the dependent fetches, and a node array
+// of a third the size (5 M triangles: 320 MB -> 94 MB, inside the 256 MB Infinity Cache).  The leaf's exact box sits in front
 // of a copy of its primitive in a leaf-ordered table: one fetch gives the reference's box test and the intersector's operands.
 //
 // Node record (104 B; WideNode in rt_wide.hip writes it):

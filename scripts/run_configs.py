@@ -14,7 +14,7 @@ Per config: Msamples/s and Mrays/s over `passes` passes (two batch slots in flig
                       box 70/112, capsule 60/32, disk 42/48, cylinder 60/32), plane 12/24 for the unbounded InfinitePlane tests
     frac_valu = flops / time / 157.3 TFLOP/s (FP32 vector peak; the kernels are built -ffp-contract=off, so half of it is their ceiling)
     frac_hbm_model = bytes / time / 8 TB/s — the §8d byte model counts every node and primitive fetch, cached or not (8-wide trees:
-                     80 B per node visit spread over its child slots in use, 32 B per leaf box, see wide_model)
+                     80 B read per node visit (of a 104-B record) spread over its child slots in use, 32 B per leaf box, see wide_model)
     frac_hbm_pmc   = ((FETCH_SIZE + WRITE_SIZE) * 1024 per launch + half the coalesced state reads) / time / 8 TB/s when --traffic names a
                      PMC file for this config (scripts/pmc_passes.sh with BENCH_CMD="python3 scripts/run_configs.py cN --short", then
                      scripts/pmc_traffic.py, which explains the calibration: gathers of 64-B node records are counted in full, coalesced
