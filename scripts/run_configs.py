@@ -108,10 +108,18 @@ def run_config(c, short=False, traffic=None, exact=False):
     s0 = snap(job)
     t0 = time.perf_counter(); job.RenderPasses(0, passes, 1); job.UpdateImage(); dt = time.perf_counter() - t0
     s1 = snap(job)
-    d = {k: s1[k] - s0[k] for k in s0}
+    reps = 1
+    if dt < 0.25:      # a job of milliseconds (config 1: 8.3 M samples) measures the clocks ramping up, not the kernels: the same job again until half a second has been timed
+        reps = int(0.5 / max(dt, 1e-4)) + 1
+        s0 = snap(job)
+        t0 = time.perf_counter()
+        for i in range(reps): job.RenderPasses((i + 1) * passes, passes, 1)
+        job.UpdateImage(); dt = (time.perf_counter() - t0) / reps
+        s1 = snap(job)
+    d = {k: (s1[k] - s0[k]) // reps for k in s0}
     rays, sh = d["RayCount"], d["ShadowRays"]
     info = dev.Info()
-    out = {"config": c, "workload": label, "passes": passes, "seconds": dt, "msamples_per_s": W * H * passes / dt / 1e6,
+    out = {"config": c, "workload": label, "passes": passes, "seconds": dt, "jobs_timed": reps, "msamples_per_s": W * H * passes / dt / 1e6,
            "mode": "exact light sampling + exact occlusion" if exact else "default",
            "mrays_per_s": {"closest": rays / dt / 1e6, "shadow": sh / dt / 1e6},
            "box_tests_per_closest_ray": d["NodeVisits"] / max(rays, 1), "prim_tests_per_closest_ray": d["PrimTests"] / max(rays, 1),
