@@ -38,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PASSES_PER_STEP = 256           # one step = BASELINE config 2 in full: 1920 x 1080 x 256 spp (four 64-pass batches, two in flight)
-PASSES_PER_BATCH = 64     # passes per wavefront batch (133 M paths, 24 GB of path state); the library keeps two batches in flight
+PASSES_PER_BATCH = int(os.environ.get("RT_BENCH_PPB", "64"))     # passes per wavefront batch (64: 133 M paths, 24 GB of path state); the library keeps two batches in flight (RT_BENCH_PPB: A/B runs)
 WIDTH, HEIGHT = 1920, 1080
 MAX_DEPTH, LIGHT_SAMPLES = 10, 2
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
