@@ -882,6 +882,9 @@ template <class C> struct ShadowPersistentWideTune { static constexpr int min_wa
 #ifndef RT_SPQ_WAVES
 #define RT_SPQ_WAVES 1
 #endif
+#ifndef RT_SPW_KEEP_CONTRIBUTION
+#define RT_SPW_KEEP_CONTRIBUTION 1
+#endif
 #ifdef RT_SPW_PROF
 constexpr uint32_t SPW_COUNTS = 0;      // (measurement builds: the three counters hold rounds and lanes, see below)
 #else
@@ -908,7 +911,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
     f3 wp = mk3(0, 0, 0), nrm = mk3(0, 0, 1), in = mk3(0, 0, 0);
     RngKey key = path_key(rd, 0);
     const rt_material* m = nullptr; bool phong = false;
-    col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0);
+    col3 sum = mkc(0, 0, 0), spec_sum = mkc(0, 0, 0), cdd = mkc(0, 0, 0), unocc = mkc(0, 0, 0);      // unocc: what the ray in flight adds if it reaches its light (known since the mute check)
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
     bool again = false;                  // the ray in flight gets a second look through grown boxes if it comes out unoccluded (any_box)
     AnyBox box = make_any_box(r, 0.0f, 1.0f);                                          // binary trees
@@ -933,7 +936,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
                 bool advance = true;
                 if (!second) {
                     col3 c = mkc(0, 0, 0);
-                    if (!occluded) c = light_contribution<EXACT>(l, kMax);
+                    if (!occluded) c = RT_SPW_KEEP_CONTRIBUTION && RT_SKIP_MUTE_RAYS && rd.skip_mute_rays && !phong ? unocc : light_contribution<EXACT>(l, kMax);      // (kept from the mute check below: the same function of the same operands)
                     if (!phong) sum = sum + c;
                     else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) { cdd = c * fabsf(dot(r.d, nrm)); second = true; advance = false; }
                 } else if constexpr (RT_HAS_MAT(C, RT_MAT_PHONG)) {              // PhongMaterial.cs:50-65
@@ -988,6 +991,7 @@ __global__ void __launch_bounds__(TREE == TREE_LDS ? LDS_BLOCK_SHADOW : BLOCK, E
                 if (RT_SKIP_MUTE_RAYS && rd.skip_mute_rays && !phong) {         // a ray whose light cannot change the sum is not traced (see k_shadow): accounted as if occluded, the same bits
                     const col3 unoccluded = light_contribution<EXACT>(sc.lights + li, kMax), t = sum + unoccluded;
                     occluded = t.r == sum.r && t.g == sum.g && t.b == sum.b;
+                    if (RT_SPW_KEEP_CONTRIBUTION) unocc = unoccluded;
                 }
                 for (uint32_t i = 0; i < sc.n_unbounded && !occluded; i++) {
                     uint32_t code = sc.obj_code[sc.unbounded[i]]; prims += SPW_COUNTS;
